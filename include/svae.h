@@ -1,0 +1,175 @@
+/*
+ * svae.h -- C ABI of the MI355X (gfx950) spatial-VAE decoder hot path.
+ *
+ * The reference (cfframe/spatial-VAE) has no FFI layer: its boundary for this path is the
+ * Python callable p_net(x.contiguous(), z) = SpatialGenerator.forward
+ * (spatial_vae/models.py:90-132; call sites train_mnist.py:77, train_galaxy.py:115,
+ * train_particles.py:102) together with the lines of eval_minibatch around it that build
+ * the coordinates and score the output.  Each entry point below names the reference lines
+ * it replaces.  INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller, fp32 unless stated, contiguous
+ *     row-major in the shapes given (the shapes torch gives the reference's tensors);
+ *   - nothing here allocates, synchronises or throws: work is enqueued on `stream` (a
+ *     hipStream_t; NULL = the default stream) and the call returns; 0 = success, a negative
+ *     SVAE_E_* code otherwise, with text in svae_last_error() (thread-local);
+ *   - the library is stateless and re-entrant: one process per GPU, any number of streams;
+ *   - `saved` (svae_saved_bytes) carries activations from forward to backward and must stay
+ *     untouched in between; `ws` (svae_workspace_bytes) is scratch, free to reuse after the
+ *     call's work has completed on the stream.  Both must be 256-byte aligned.
+ */
+#ifndef SVAE_H
+#define SVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVAE_ABI_VERSION 1
+#define SVAE_MAX_HIDDEN 7 /* hidden H x H layers = num_layers - 1 */
+#define SVAE_MAX_OUT 4    /* n_out (channels) */
+
+typedef void* svae_stream_t; /* hipStream_t */
+
+enum {
+    SVAE_OK = 0,
+    SVAE_E_INVALID = -1,   /* bad descriptor / null pointer / unsupported size */
+    SVAE_E_WORKSPACE = -2, /* ws_bytes too small or misaligned */
+    SVAE_E_LAUNCH = -3     /* HIP reported an error at launch */
+};
+
+/* activation = the nn.Module class handed to SpatialGenerator (models.py:58, 77-83) */
+enum { SVAE_ACT_TANH = 0, SVAE_ACT_LEAKYRELU = 1, SVAE_ACT_RELU = 2, SVAE_ACT_SIGMOID = 3 };
+enum {
+    SVAE_FLAG_RESID = 1,    /* resid=True: hidden layers are ResidLinear (models.py:13-21) */
+    SVAE_FLAG_BILINEAR = 2, /* bilinear=True (models.py:74-75, 114-121) */
+    SVAE_FLAG_SOFTPLUS = 4  /* softplus=True on output channel 0 (models.py:129-130) */
+};
+
+/* Constructor arguments of SpatialGenerator (models.py:58-59) plus the batch geometry. */
+typedef struct svae_desc {
+    int32_t B;      /* images in this call */
+    int32_t N;      /* coordinates (pixels) per image */
+    int32_t H;      /* hidden_dim */
+    int32_t L;      /* num_layers >= 1 (number of hidden activations) */
+    int32_t Zd;     /* latent_dim handed to the decoder (0 = no latent_linear) */
+    int32_t C;      /* n_out, 1..SVAE_MAX_OUT */
+    int32_t in_dim; /* 2, or 5 with expand_coords (models.py:65-67, 99-102) */
+    int32_t act;    /* SVAE_ACT_* */
+    int32_t flags;  /* SVAE_FLAG_* */
+} svae_desc;
+
+/* Parameters exactly as nn.Linear / nn.Bilinear store them (state-dict names in comments). */
+typedef struct svae_params {
+    const float* coord_w;                   /* coord_linear.weight (H, in_dim) */
+    const float* coord_b;                   /* coord_linear.bias   (H) */
+    const float* latent_w;                  /* latent_linear.weight (H, Zd); NULL iff Zd == 0 */
+    const float* bilinear_w;                /* bilinear.weight (H, in_dim, Zd); NULL unless BILINEAR */
+    const float* hidden_w[SVAE_MAX_HIDDEN]; /* layers.<i>[.linear].weight (H, H), L-1 entries */
+    const float* hidden_b[SVAE_MAX_HIDDEN]; /* layers.<i>[.linear].bias   (H) */
+    const float* out_w;                     /* last Linear weight (C, H) */
+    const float* out_b;                     /* last Linear bias   (C) */
+} svae_params;
+
+/* Same shapes; every non-NULL entry is OVERWRITTEN with d(loss)/d(parameter). */
+typedef struct svae_grads {
+    float* coord_w;
+    float* coord_b;
+    float* latent_w;
+    float* bilinear_w;
+    float* hidden_w[SVAE_MAX_HIDDEN];
+    float* hidden_b[SVAE_MAX_HIDDEN];
+    float* out_w;
+    float* out_b;
+} svae_grads;
+
+/*
+ * Where the decoder's coordinates come from.
+ *   coords != NULL : explicit (B, N, 2), the generic SpatialGenerator.forward(x, z) entry.
+ *   coords == NULL : built on the fly from the shared grid and the per-image pose, replacing
+ *                    x.expand + rot + bmm + translate of eval_minibatch (train_mnist.py:26, 42-74;
+ *                    train_galaxy.py:73-110; train_particles.py:60-97):
+ *                        x''[b,i] = grid[i] @ [[cos t_b, sin t_b], [-sin t_b, cos t_b]] + dx[b]
+ *                    theta NULL = no rotation, dx NULL = no translation (dx already times dx_scale).
+ */
+typedef struct svae_pose {
+    const float* coords; /* (B, N, 2) or NULL */
+    const float* grid;   /* (N, 2), used when coords == NULL */
+    const float* theta;  /* (B) or NULL */
+    const float* dx;     /* (B, 2) or NULL */
+} svae_pose;
+
+/* Gradient sinks matching svae_pose; NULL entries are skipped. */
+typedef struct svae_pose_grads {
+    float* dcoords; /* (B, N, 2): d/d(coords) -- allowed in either mode */
+    float* dtheta;  /* (B):    sum_i <dx''[b,i], d(rot)/d(theta) grid[i]> */
+    float* ddx;     /* (B, 2): sum_i dx''[b,i] */
+} svae_pose_grads;
+
+int svae_abi_version(void);
+const char* svae_last_error(void);
+
+/* Bytes of the forward->backward carry and of the scratch area for a descriptor. */
+size_t svae_saved_bytes(const svae_desc* d);
+size_t svae_workspace_bytes(const svae_desc* d);
+
+/*
+ * Decoder forward: replaces SpatialGenerator.forward (models.py:90-132) and, when
+ * pose->coords == NULL, the coordinate transform in front of it (see svae_pose).
+ *   z      (B, Zd)     latent handed to the decoder (ignored when Zd == 0)
+ *   y      (B, N, C)   module output: sigmoid(logits), channel 0 through softplus if flagged
+ *   logits (B, N, C)   input of the final Sigmoid = output of layers[-2]; may be NULL for
+ *                      inference (svae_decoder_backward needs it)
+ *   saved              svae_saved_bytes(d) bytes, or NULL for inference-only calls
+ */
+int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z,
+                         float* y, float* logits, void* saved, void* ws, size_t ws_bytes,
+                         svae_stream_t stream);
+
+/*
+ * Decoder backward: replaces the autograd replay of the lines above.
+ *   logits    (B, N, C) the forward's pre-Sigmoid output (the wrapper keeps it, as autograd
+ *             keeps the Sigmoid's result in the reference)
+ *   dy        (B, N, C) d(loss)/d(y), y being the module output
+ *   dy_scale  (B) or NULL: per-image factor applied to dy (the upstream gradient of a
+ *             per-image log-likelihood; lets a fused loss hand over d(loglik_b)/d(y) unscaled)
+ *   grads     every non-NULL field is overwritten
+ *   dz        (B, Zd) or NULL
+ *   pg        coordinate / pose gradients, or NULL
+ */
+int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z,
+                          const float* logits, const float* dy, const float* dy_scale, const void* saved,
+                          const svae_grads* grads, float* dz, const svae_pose_grads* pg, void* ws,
+                          size_t ws_bytes, svae_stream_t stream);
+
+/*
+ * Per-pixel Bernoulli log-likelihood with torch's clamps: replaces
+ * -F.binary_cross_entropy(y_hat, y) * size (train_mnist.py:78-81; train_galaxy.py:116-119)
+ * in per-image form (the reference's scalar is the mean of loglik over the batch).
+ *   y_hat, target (B, n) with n = N*C;  loglik (B);  dll_dy (B, n) = d(loglik_b)/d(y_hat), may be NULL
+ */
+int svae_bce_loglik(int32_t B, int32_t n, const float* y_hat, const float* target, float* loglik,
+                    float* dll_dy, svae_stream_t stream);
+
+/*
+ * Gaussian log-likelihood of train_particles.py:102-139, per image, including its layout quirk
+ * (with C == 2 the first N entries of the channel-interleaved row are the mean, the last N the
+ * log-variance), the optional CTF filter (depth-wise k x k cross-correlation of the mean image,
+ * zero padding k/2; train_particles.py:112-119; C == 1 only) and the optional pixel mask
+ * (train_particles.py:126-132).
+ *   y_params (B, N*C); target (B, N); mask (N) bytes or NULL; ctf (B, k, k) or NULL
+ *   loglik (B); dll_dy (B, N*C) may be NULL; ws: svae_gaussian_workspace_bytes(B, N) when ctf != NULL
+ */
+size_t svae_gaussian_workspace_bytes(int32_t B, int32_t N);
+int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params, const float* target,
+                         const uint8_t* mask, const float* ctf, int32_t k, float* loglik, float* dll_dy,
+                         void* ws, size_t ws_bytes, svae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVAE_H */

@@ -1,0 +1,81 @@
+"""ctypes binding of include/svae.h.  Loading fails loudly: there is no fallback path."""
+import ctypes
+import os
+
+# torch ships its own libamdhip64.so.7; it must be in the process first so that this library's
+# NEEDED entry of the same soname binds to THAT runtime (two HIP runtimes in one process do not
+# share a device context: launches then fail with "no ROCm-capable device").
+import torch  # noqa: F401
+
+from .build import library_path
+
+MAX_HIDDEN = 7
+ACT = {"tanh": 0, "leakyrelu": 1, "relu": 2, "sigmoid": 3}
+FLAG_RESID, FLAG_BILINEAR, FLAG_SOFTPLUS = 1, 2, 4
+
+EXPORTS = ("svae_abi_version", "svae_last_error", "svae_saved_bytes", "svae_workspace_bytes",
+           "svae_decoder_forward", "svae_decoder_backward", "svae_bce_loglik",
+           "svae_gaussian_workspace_bytes", "svae_gaussian_loglik")
+
+
+class Desc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "N", "H", "L", "Zd", "C", "in_dim", "act", "flags")]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("coord_w", ctypes.c_void_p), ("coord_b", ctypes.c_void_p), ("latent_w", ctypes.c_void_p),
+                ("bilinear_w", ctypes.c_void_p), ("hidden_w", ctypes.c_void_p * MAX_HIDDEN),
+                ("hidden_b", ctypes.c_void_p * MAX_HIDDEN), ("out_w", ctypes.c_void_p), ("out_b", ctypes.c_void_p)]
+
+
+class Pose(ctypes.Structure):
+    _fields_ = [("coords", ctypes.c_void_p), ("grid", ctypes.c_void_p), ("theta", ctypes.c_void_p),
+                ("dx", ctypes.c_void_p)]
+
+
+class PoseGrads(ctypes.Structure):
+    _fields_ = [("dcoords", ctypes.c_void_p), ("dtheta", ctypes.c_void_p), ("ddx", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if it was never built: the product path has no other backend."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("spatial_vae_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or spatial_vae_amd.build()); there is no fallback implementation" % path)
+    L = ctypes.CDLL(path)
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32
+    L.svae_abi_version.restype = ctypes.c_int
+    L.svae_last_error.restype = ctypes.c_char_p
+    L.svae_saved_bytes.restype = sz
+    L.svae_saved_bytes.argtypes = [ctypes.POINTER(Desc)]
+    L.svae_workspace_bytes.restype = sz
+    L.svae_workspace_bytes.argtypes = [ctypes.POINTER(Desc)]
+    L.svae_decoder_forward.restype = ctypes.c_int
+    L.svae_decoder_forward.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Params), ctypes.POINTER(Pose), vp,
+                                       vp, vp, vp, vp, sz, vp]
+    L.svae_decoder_backward.restype = ctypes.c_int
+    L.svae_decoder_backward.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Params), ctypes.POINTER(Pose), vp,
+                                        vp, vp, vp, vp, ctypes.POINTER(Params), vp, ctypes.POINTER(PoseGrads),
+                                        vp, sz, vp]
+    L.svae_bce_loglik.restype = ctypes.c_int
+    L.svae_bce_loglik.argtypes = [i32, i32, vp, vp, vp, vp, vp]
+    L.svae_gaussian_workspace_bytes.restype = sz
+    L.svae_gaussian_workspace_bytes.argtypes = [i32, i32]
+    L.svae_gaussian_loglik.restype = ctypes.c_int
+    L.svae_gaussian_loglik.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]
+    if L.svae_abi_version() != 1:
+        raise RuntimeError("spatial_vae_amd: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("svae: %s (code %d)" % (lib().svae_last_error().decode(), rc))

@@ -1,0 +1,426 @@
+// C-ABI of the gfx950 spatial-VAE decoder (see include/svae.h): argument checks, workspace
+// planning and the kernel launch sequences.  Nothing here allocates or synchronises.
+#include <stdarg.h>
+#include <stdio.h>
+#include <type_traits>
+
+#include "common.h"
+#include "dense.h"
+#include "elementwise.h"
+
+using namespace svae;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
+    template <class T>
+    T* take(size_t count) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct Plan {
+    // saved (forward -> backward)
+    float* act[SVAE_MAX_HIDDEN + 1];
+    // workspace
+    float* wf[SVAE_MAX_HIDDEN];
+    float* wb[SVAE_MAX_HIDDEN];
+    float* tab;
+    float4* posebuf;
+    float* dh[2];
+    float* do_p;
+    float* slab;
+    float* bslab;
+    float* wpart;
+    float* sgpart;
+    float* sgimg;
+    float* dcoords;
+    // split geometry
+    int wg_nblk1, wg_S;
+    long ob_oct_per_chunk;
+    int ob_chunks;
+    int l0_oct_per_chunk, l0_chunks_per_image;
+    size_t saved_bytes, ws_bytes;
+};
+
+Plan make_plan(const Geo& g, void* saved, void* ws) {
+    Plan p;
+    const size_t MH = (size_t)g.Mp * g.Hp;
+    Carver cs(saved);
+    for (int l = 0; l < g.L; ++l) p.act[l] = cs.take<float>(MH);
+    p.saved_bytes = cs.off;
+
+    p.wg_nblk1 = (g.ntile + 7) / 8;
+    {
+        const long nblk = (long)p.wg_nblk1 * p.wg_nblk1;
+        long S = 256 / nblk;
+        if (S < 1) S = 1;
+        long cap = g.noct / 8;
+        if (cap < 1) cap = 1;
+        if (S > cap) S = cap;
+        p.wg_S = (int)S;
+    }
+    {
+        long rc = g.noct / 32;
+        if (rc < 1) rc = 1;
+        if (rc > 512) rc = 512;
+        p.ob_oct_per_chunk = (g.noct + rc - 1) / rc;
+        p.ob_chunks = (int)((g.noct + p.ob_oct_per_chunk - 1) / p.ob_oct_per_chunk);
+    }
+    {
+        const int oimg = g.Npad / 8;
+        const int xb = (g.Hp * 2 + 255) / 256;
+        long want = (2048 + (long)g.B * xb - 1) / ((long)g.B * xb);
+        if (want < 1) want = 1;
+        int opc = (int)((oimg + want - 1) / want);
+        if (opc < 8) opc = 8;
+        if (opc > oimg) opc = oimg;
+        p.l0_oct_per_chunk = opc;
+        p.l0_chunks_per_image = (oimg + opc - 1) / opc;
+    }
+
+    Carver cw(ws);
+    for (int l = 0; l + 1 < g.L; ++l) {
+        p.wf[l] = cw.take<float>((size_t)g.Hp * g.Hp);
+        p.wb[l] = cw.take<float>((size_t)g.Hp * g.Hp);
+    }
+    p.tab = cw.take<float>((size_t)g.B * g.Hp * kSlots);
+    p.posebuf = cw.take<float4>(g.B);
+    p.dh[0] = cw.take<float>(MH);
+    p.dh[1] = cw.take<float>(MH);
+    p.do_p = cw.take<float>((size_t)g.C * g.Mp);
+    p.slab = cw.take<float>((size_t)p.wg_S * g.Hp * g.Hp);
+    p.bslab = cw.take<float>((size_t)p.wg_S * 2 * g.Hp);
+    p.wpart = cw.take<float>((size_t)p.ob_chunks * 2 * g.C * g.Hp);
+    p.sgpart = cw.take<float>((size_t)g.B * p.l0_chunks_per_image * g.Hp * 2 * kSlots);
+    p.sgimg = cw.take<float>((size_t)g.B * g.Hp * kSlots);
+    p.dcoords = cw.take<float>((size_t)g.B * g.N * 2);
+    p.ws_bytes = (cw.off + 255) & ~size_t(255);
+    return p;
+}
+
+int check_desc(const svae_desc* d) {
+    if (!d) return fail(SVAE_E_INVALID, "null descriptor");
+    if (d->B < 1 || d->N < 1 || d->H < 1) return fail(SVAE_E_INVALID, "B, N, H must be positive (got %d, %d, %d)", d->B, d->N, d->H);
+    if (d->L < 1 || d->L - 1 > SVAE_MAX_HIDDEN) return fail(SVAE_E_INVALID, "num_layers %d outside 1..%d", d->L, SVAE_MAX_HIDDEN + 1);
+    if (d->C < 1 || d->C > SVAE_MAX_OUT) return fail(SVAE_E_INVALID, "n_out %d outside 1..%d", d->C, SVAE_MAX_OUT);
+    if (d->Zd < 0) return fail(SVAE_E_INVALID, "negative latent_dim");
+    if (d->in_dim != 2 && d->in_dim != 5) return fail(SVAE_E_INVALID, "in_dim must be 2 or 5 (got %d)", d->in_dim);
+    if (d->act < SVAE_ACT_TANH || d->act > SVAE_ACT_SIGMOID) return fail(SVAE_E_INVALID, "unknown activation %d", d->act);
+    if ((d->flags & SVAE_FLAG_BILINEAR) && d->Zd == 0) return fail(SVAE_E_INVALID, "bilinear needs latent_dim > 0");
+    if ((long)d->B * ((d->N + 31) / 32 * 32) > (1L << 30)) return fail(SVAE_E_INVALID, "B*N too large");
+    return SVAE_OK;
+}
+
+int check_params(const svae_desc* d, const svae_params* p) {
+    if (!p || !p->coord_w || !p->coord_b || !p->out_w || !p->out_b) return fail(SVAE_E_INVALID, "missing parameter pointer");
+    if (d->Zd > 0 && !p->latent_w) return fail(SVAE_E_INVALID, "latent_dim > 0 but latent_w is null");
+    if ((d->flags & SVAE_FLAG_BILINEAR) && !p->bilinear_w) return fail(SVAE_E_INVALID, "bilinear flag but bilinear_w is null");
+    for (int l = 0; l + 1 < d->L; ++l)
+        if (!p->hidden_w[l] || !p->hidden_b[l]) return fail(SVAE_E_INVALID, "hidden layer %d parameters are null", l);
+    return SVAE_OK;
+}
+
+int check_pose(const svae_pose* pose) {
+    if (!pose) return fail(SVAE_E_INVALID, "null pose");
+    if (!pose->coords && !pose->grid) return fail(SVAE_E_INVALID, "pose needs coords or grid");
+    return SVAE_OK;
+}
+
+int check_ws(const Plan& p, const void* ws, size_t ws_bytes) {
+    if (!ws) return fail(SVAE_E_WORKSPACE, "null workspace");
+    if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(SVAE_E_WORKSPACE, "workspace not 256-byte aligned");
+    if (ws_bytes < p.ws_bytes) return fail(SVAE_E_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, p.ws_bytes);
+    return SVAE_OK;
+}
+
+int launch_status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SVAE_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SVAE_OK;
+}
+
+inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
+
+PoseArgs pose_args(const svae_pose* pose) {
+    PoseArgs pa;
+    pa.coords = pose->coords;
+    pa.grid = pose->grid;
+    pa.theta = pose->coords ? nullptr : pose->theta;
+    pa.dx = pose->coords ? nullptr : pose->dx;
+    return pa;
+}
+
+RowGeo row_geo(const Geo& g) {
+    RowGeo r;
+    r.N = g.N; r.Npad = g.Npad; r.Hp = g.Hp; r.in_dim = g.in_dim; r.act = g.act; r.B = g.B;
+    return r;
+}
+
+// tables + packed weights: needed by both directions, rebuilt per call (a few MB of traffic)
+void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const PoseArgs& pa, const float* z, hipStream_t st) {
+    const long nt = (long)g.B * g.Hp;
+    hipLaunchKernelGGL(tables_kernel, dim3(blocks_for(nt > g.B ? nt : g.B)), dim3(256), 0, st, p->coord_w, p->coord_b,
+                       g.Zd > 0 ? p->latent_w : nullptr, (g.flags & SVAE_FLAG_BILINEAR) ? p->bilinear_w : nullptr, z,
+                       pl.tab, pl.posebuf, pa, g.B, g.H, g.Hp, g.Zd, g.in_dim);
+    for (int l = 0; l + 1 < g.L; ++l)
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks_for((long)g.Hp * g.Hp)), dim3(256), 0, st, p->hidden_w[l],
+                           pl.wf[l], pl.wb[l], g.H, g.Hp);
+}
+
+template <bool DGRAD>
+void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)((g.tiles + 3) / 4)), block(256);
+    if (g.ntile % 16 == 0) {
+        hipLaunchKernelGGL((dense_kernel<16, DGRAD>), grid, block, 2 * 2 * 512 * 8 * 4, st, a);
+    } else if (g.ntile % 8 == 0) {
+        hipLaunchKernelGGL((dense_kernel<8, DGRAD>), grid, block, 2 * 4 * 256 * 8 * 4, st, a);
+    } else if (g.ntile % 4 == 0) {
+        hipLaunchKernelGGL((dense_kernel<4, DGRAD>), grid, block, 2 * 4 * 128 * 8 * 4, st, a);
+    } else if (g.ntile % 2 == 0) {
+        hipLaunchKernelGGL((dense_kernel<2, DGRAD>), grid, block, 2 * 4 * 64 * 8 * 4, st, a);
+    } else {
+        hipLaunchKernelGGL((dense_kernel<1, DGRAD>), grid, block, 2 * 4 * 32 * 8 * 4, st, a);
+    }
+}
+
+template <int ACT>
+void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
+    const long total = g.noct * g.Hp * 2;
+    hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(total)), dim3(256), 0, st, pa, pl.posebuf, pl.tab, a0,
+                       row_geo(g), total);
+}
+
+template <int C>
+void launch_out_fwd(const Geo& g, const float* a, const svae_params* p, float* y, float* logits, hipStream_t st) {
+    long nb = (g.noct + 3) / 4;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL((out_fwd_kernel<C>), dim3((unsigned)nb), dim3(256), 0, st, a, p->out_w, p->out_b, y, logits,
+                       row_geo(g), g.H, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, g.noct);
+}
+
+template <int ACT, int C>
+void launch_out_bwd_ac(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh, hipStream_t st) {
+    hipLaunchKernelGGL((out_bwd_kernel<ACT, C>), dim3(blocks_for(g.Hp * 2), pl.ob_chunks), dim3(256), 0, st, a, pl.do_p,
+                       p->out_w, dh, pl.wpart, g.H, g.Hp, (long)g.Mp, g.noct, pl.ob_oct_per_chunk);
+}
+template <int ACT>
+void launch_out_bwd_a(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh, hipStream_t st) {
+    switch (g.C) {
+        case 1: launch_out_bwd_ac<ACT, 1>(g, pl, a, p, dh, st); break;
+        case 2: launch_out_bwd_ac<ACT, 2>(g, pl, a, p, dh, st); break;
+        case 3: launch_out_bwd_ac<ACT, 3>(g, pl, a, p, dh, st); break;
+        default: launch_out_bwd_ac<ACT, 4>(g, pl, a, p, dh, st); break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int svae_abi_version(void) { return SVAE_ABI_VERSION; }
+const char* svae_last_error(void) { return g_err; }
+
+size_t svae_saved_bytes(const svae_desc* d) {
+    if (check_desc(d) != SVAE_OK) return 0;
+    return make_plan(make_geo(*d), nullptr, nullptr).saved_bytes;
+}
+
+size_t svae_workspace_bytes(const svae_desc* d) {
+    if (check_desc(d) != SVAE_OK) return 0;
+    return make_plan(make_geo(*d), nullptr, nullptr).ws_bytes;
+}
+
+int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z, float* y,
+                         float* logits, void* saved, void* ws, size_t ws_bytes, svae_stream_t stream) {
+    int rc;
+    if ((rc = check_desc(d)) || (rc = check_params(d, p)) || (rc = check_pose(pose))) return rc;
+    if (!y) return fail(SVAE_E_INVALID, "y is null");
+    if (d->Zd > 0 && !z) return fail(SVAE_E_INVALID, "latent_dim > 0 but z is null");
+    if (saved && (reinterpret_cast<uintptr_t>(saved) & 255)) return fail(SVAE_E_WORKSPACE, "saved not 256-byte aligned");
+    const Geo g = make_geo(*d);
+    Plan pl = make_plan(g, saved, ws);
+    if ((rc = check_ws(pl, ws, ws_bytes))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PoseArgs pa = pose_args(pose);
+    if (!saved) {  // inference only: ping-pong through the (otherwise unused) gradient buffers
+        for (int l = 0; l < g.L; ++l) pl.act[l] = pl.dh[l & 1];
+    }
+
+    launch_prepare(g, pl, p, pa, z, st);
+    switch (g.act) {
+        case SVAE_ACT_TANH: launch_layer0_fwd<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st); break;
+        case SVAE_ACT_LEAKYRELU: launch_layer0_fwd<SVAE_ACT_LEAKYRELU>(g, pl, pa, pl.act[0], st); break;
+        case SVAE_ACT_RELU: launch_layer0_fwd<SVAE_ACT_RELU>(g, pl, pa, pl.act[0], st); break;
+        default: launch_layer0_fwd<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st); break;
+    }
+    for (int l = 1; l < g.L; ++l) {
+        DenseArgs a;
+        a.in = pl.act[l - 1];
+        a.wp = pl.wf[l - 1];
+        a.out = pl.act[l];
+        a.bias = p->hidden_b[l - 1];
+        a.aux = nullptr;
+        a.tiles = g.tiles;
+        a.Hp = g.Hp;
+        a.H = g.H;
+        a.act = g.act;
+        a.resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
+        launch_dense<false>(g, a, st);
+    }
+    switch (g.C) {
+        case 1: launch_out_fwd<1>(g, pl.act[g.L - 1], p, y, logits, st); break;
+        case 2: launch_out_fwd<2>(g, pl.act[g.L - 1], p, y, logits, st); break;
+        case 3: launch_out_fwd<3>(g, pl.act[g.L - 1], p, y, logits, st); break;
+        default: launch_out_fwd<4>(g, pl.act[g.L - 1], p, y, logits, st); break;
+    }
+    return launch_status("svae_decoder_forward");
+}
+
+int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z,
+                          const float* logits, const float* dy, const float* dy_scale, const void* saved,
+                          const svae_grads* grads, float* dz, const svae_pose_grads* pg, void* ws, size_t ws_bytes,
+                          svae_stream_t stream) {
+    int rc;
+    if ((rc = check_desc(d)) || (rc = check_params(d, p)) || (rc = check_pose(pose))) return rc;
+    if (!logits || !dy || !saved || !grads) return fail(SVAE_E_INVALID, "logits, dy, saved and grads are required");
+    if (d->Zd > 0 && !z) return fail(SVAE_E_INVALID, "latent_dim > 0 but z is null");
+    if (reinterpret_cast<uintptr_t>(saved) & 255) return fail(SVAE_E_WORKSPACE, "saved not 256-byte aligned");
+    const Geo g = make_geo(*d);
+    const Plan pl = make_plan(g, const_cast<void*>(saved), ws);
+    if ((rc = check_ws(pl, ws, ws_bytes))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PoseArgs pa = pose_args(pose);
+    const int resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
+
+    launch_prepare(g, pl, p, pa, z, st);
+
+    // d(loss)/d(logits) in padded row space (pad rows exactly zero)
+    if (hipMemsetAsync(pl.do_p, 0, (size_t)g.C * g.Mp * sizeof(float), st) != hipSuccess)
+        return fail(SVAE_E_LAUNCH, "memset failed");
+    hipLaunchKernelGGL(dlogits_kernel, dim3(blocks_for((long)g.B * g.N * g.C)), dim3(256), 0, st, logits, dy, dy_scale,
+                       pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
+
+    // output layer: dh_{L-1}, dW_o, db_o
+    int cur = 0;
+    const float* alast = pl.act[g.L - 1];
+    switch (g.act) {
+        case SVAE_ACT_TANH: launch_out_bwd_a<SVAE_ACT_TANH>(g, pl, alast, p, pl.dh[cur], st); break;
+        case SVAE_ACT_LEAKYRELU: launch_out_bwd_a<SVAE_ACT_LEAKYRELU>(g, pl, alast, p, pl.dh[cur], st); break;
+        case SVAE_ACT_RELU: launch_out_bwd_a<SVAE_ACT_RELU>(g, pl, alast, p, pl.dh[cur], st); break;
+        default: launch_out_bwd_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, pl.dh[cur], st); break;
+    }
+    hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C + blocks_for((long)g.C * g.H)), dim3(256), 0, st, pl.wpart, pl.do_p,
+                       grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2, (long)g.Mp);
+
+    // hidden layers, last to first
+    for (int l = g.L - 1; l >= 1; --l) {
+        if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1]) {
+            WgradArgs w;
+            w.dh = pl.dh[cur];
+            w.aprev = pl.act[l - 1];
+            w.slab = pl.slab;
+            w.bslab = pl.bslab;
+            w.noct = g.noct;
+            w.Hp = g.Hp;
+            w.nblk1 = pl.wg_nblk1;
+            hipLaunchKernelGGL(wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), 0, st, w);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
+                               grads->hidden_w[l - 1], grads->hidden_b[l - 1], g.H, g.Hp, pl.wg_S);
+        }
+        DenseArgs a;
+        a.in = pl.dh[cur];
+        a.wp = pl.wb[l - 1];
+        a.out = pl.dh[cur ^ 1];
+        a.bias = nullptr;
+        a.aux = pl.act[l - 1];
+        a.tiles = g.tiles;
+        a.Hp = g.Hp;
+        a.H = g.H;
+        a.act = g.act;
+        a.resid = resid;
+        launch_dense<true>(g, a, st);
+        cur ^= 1;
+    }
+
+    // coordinate layer
+    const float* dh0 = pl.dh[cur];
+    hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0, st,
+                       pa, pl.posebuf, dh0, pl.sgpart, row_geo(g), pl.l0_oct_per_chunk, pl.l0_chunks_per_image);
+    hipLaunchKernelGGL(sg_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp * kSlots)), dim3(256), 0, st, pl.sgpart, pl.sgimg,
+                       g.B, g.Hp, pl.l0_chunks_per_image);
+    const bool bil = (g.flags & SVAE_FLAG_BILINEAR) != 0;
+    hipLaunchKernelGGL(layer0_param_grads_kernel, dim3(blocks_for(g.H)), dim3(256), 0, st, pl.sgimg, z, grads->coord_w,
+                       grads->coord_b, g.Zd > 0 ? grads->latent_w : nullptr, bil ? grads->bilinear_w : nullptr, g.B, g.H,
+                       g.Hp, g.Zd, g.in_dim);
+    if (dz && g.Zd > 0)
+        hipLaunchKernelGGL(dz_kernel, dim3(g.B), dim3(256), 0, st, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr, dz,
+                           g.H, g.Hp, g.Zd, g.in_dim);
+
+    if (pg && (pg->dcoords || pg->dtheta || pg->ddx)) {
+        float* dc = pg->dcoords ? pg->dcoords : pl.dcoords;
+        long nb = (g.noct + 3) / 4;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(layer0_bwd_coords_kernel, dim3((unsigned)nb), dim3(256), 0, st, pa, pl.posebuf, dh0, pl.tab, dc,
+                           row_geo(g), g.noct);
+        if (pg->dtheta || pg->ddx) {
+            if (pose->coords) return fail(SVAE_E_INVALID, "dtheta/ddx requested but the pose was given as explicit coords");
+            hipLaunchKernelGGL(pose_bwd_kernel, dim3(g.B), dim3(256), 0, st, dc, pose->grid, pl.posebuf, pg->dtheta, pg->ddx,
+                               g.N);
+        }
+    }
+    return launch_status("svae_decoder_backward");
+}
+
+int svae_bce_loglik(int32_t B, int32_t n, const float* y_hat, const float* target, float* loglik, float* dll_dy,
+                    svae_stream_t stream) {
+    if (B < 1 || n < 1 || !y_hat || !target || !loglik) return fail(SVAE_E_INVALID, "svae_bce_loglik: bad arguments");
+    hipLaunchKernelGGL(bce_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), y_hat, target, loglik, dll_dy, n);
+    return launch_status("svae_bce_loglik");
+}
+
+size_t svae_gaussian_workspace_bytes(int32_t B, int32_t N) {
+    if (B < 1 || N < 1) return 0;
+    return (((size_t)B * N * sizeof(float) + 255) & ~size_t(255)) * 2;
+}
+
+int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params, const float* target,
+                         const uint8_t* mask, const float* ctf, int32_t k, float* loglik, float* dll_dy, void* ws,
+                         size_t ws_bytes, svae_stream_t stream) {
+    if (B < 1 || N < 1 || !y_params || !target || !loglik) return fail(SVAE_E_INVALID, "svae_gaussian_loglik: bad arguments");
+    if (C != 1 && C != 2) return fail(SVAE_E_INVALID, "Gaussian likelihood needs n_out 1 or 2 (got %d)", C);
+    float* filt = nullptr;
+    float* dflt = nullptr;
+    if (ctf) {
+        // the reference applies the filter to the variance without groups= and raises
+        if (C != 1) return fail(SVAE_E_INVALID, "CTF with fit-noise has no defined result in the reference");
+        const int n = (int)(sqrt((double)N) + 0.5);
+        if (n * n != N) return fail(SVAE_E_INVALID, "CTF needs a square image (N = %d)", N);
+        if (k < 1 || (k & 1) == 0) return fail(SVAE_E_INVALID, "CTF filter size must be odd (got %d)", k);
+        const size_t half = ((size_t)B * N * sizeof(float) + 255) & ~size_t(255);
+        if (!ws || ws_bytes < 2 * half) return fail(SVAE_E_WORKSPACE, "svae_gaussian_loglik: workspace too small");
+        filt = static_cast<float*>(ws);
+        dflt = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
+    }
+    hipLaunchKernelGGL(gaussian_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), y_params, target, mask, ctf,
+                       k, loglik, dll_dy, filt, dflt, N, C);
+    return launch_status("svae_gaussian_loglik");
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// Shared device/host definitions for the gfx950 spatial-VAE decoder kernels.
+//
+// ROW SPACE.  Every image is padded to whole 32-row tiles: Npad = 32*ceil(N/32) and the
+// padded row index of pixel i of image b is  mp = b*Npad + i.  A 32-row MFMA tile therefore
+// never straddles two images, so the per-image quantities (pose, latent projection) are
+// wave-uniform.  Pad rows carry finite garbage forward and exact zeros backward (their
+// upstream gradient is zero), so they never reach a result.
+//
+// ACTIVATION LAYOUT ("octet-major").  An (Mp x F) activation / gradient tensor is stored as
+// [Mp/8][F][8]: element (m, f) lives at ((m>>3)*F + f)*8 + (m&7).  F = Hp = H rounded up
+// to 32.  Why: in the 32x32x2 fp32 MFMA a lane supplies ONE value per k-step, and a 32x32
+// accumulator holds, per lane, four consecutive rows of one column.  With rows grouped by 8
+//   * the GEMM epilogues store their accumulators as 16-byte vectors, 1 KiB contiguous per
+//     wave instruction (lane = column, the 4 consecutive rows are the vector);
+//   * the weight-gradient GEMM, which contracts over rows, loads both operands the same way
+//     (16-byte vectors, 1 KiB contiguous), four k-steps per load;
+//   * the forward / data-gradient GEMMs, which contract over features, read the row operand
+//     with one dword per lane and k-step: 4 x 64-byte segments per wave instruction, at a
+//     rate (256 B per 1024 MFMA cycles) that is nowhere near a limit.
+// Packed weights use the same format with the contraction index in the role of m.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svae.h"
+
+namespace svae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSlots = 8;     // floats per (image, feature) entry of the first-layer table
+constexpr int kBiasSlot = 5;  // slot holding b_c[k] + (W_z z_b)[k]; slots 0..4 = effective coord weights
+
+struct Geo {
+    int B, N, H, L, Zd, C, in_dim, act, flags;
+    int Timg;   // 32-row tiles per image
+    int Npad;   // 32*Timg
+    int Mp;     // B*Npad padded rows
+    int Hp;     // H rounded up to 32
+    int ntile;  // Hp/32 feature tiles
+    long noct;  // Mp/8 row octets
+    long tiles; // Mp/32 row tiles
+};
+
+inline Geo make_geo(const svae_desc& d) {
+    Geo g;
+    g.B = d.B; g.N = d.N; g.H = d.H; g.L = d.L; g.Zd = d.Zd; g.C = d.C;
+    g.in_dim = d.in_dim; g.act = d.act; g.flags = d.flags;
+    g.Timg = (d.N + 31) / 32;
+    g.Npad = g.Timg * 32;
+    g.Mp = d.B * g.Npad;
+    g.Hp = (d.H + 31) / 32 * 32;
+    g.ntile = g.Hp / 32;
+    g.noct = (long)g.Mp / 8;
+    g.tiles = (long)g.Mp / 32;
+    return g;
+}
+
+// Per-image pose handed to kernels by value (pointers may be null).
+struct PoseArgs {
+    const float* coords;  // (B,N,2) or null
+    const float* grid;    // (N,2)
+    const float* theta;   // (B) or null
+    const float* dx;      // (B,2) or null
+};
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// tanh(x) = 1 - 2/(exp(2x)+1); v_exp_f32 + v_rcp_f32 (1 ulp each).  Absolute error ~1e-7 over the
+// whole range, saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1).
+__device__ __forceinline__ float fast_tanh(float x) {
+    float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);  // 2*log2(e)
+    return 1.0f - 2.0f * fast_rcp(t + 1.0f);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    float t = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return fast_rcp(1.0f + t);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float h) {
+    if (ACT == SVAE_ACT_TANH) return fast_tanh(h);
+    if (ACT == SVAE_ACT_LEAKYRELU) return h > 0.0f ? h : 0.01f * h;
+    if (ACT == SVAE_ACT_RELU) return h > 0.0f ? h : 0.0f;
+    return fast_sigmoid(h);
+}
+// derivative of the activation expressed through its OUTPUT a (what is kept in HBM)
+template <int ACT>
+__device__ __forceinline__ float act_grad(float a) {
+    if (ACT == SVAE_ACT_TANH) return 1.0f - a * a;
+    if (ACT == SVAE_ACT_LEAKYRELU) return a > 0.0f ? 1.0f : 0.01f;
+    if (ACT == SVAE_ACT_RELU) return a > 0.0f ? 1.0f : 0.0f;
+    return a * (1.0f - a);
+}
+
+// coordinates of pixel i of image b (i < N), from explicit coords or grid + pose
+__device__ __forceinline__ float2 pixel_coord(const PoseArgs& p, int b, int i, int N, float c, float s, float dx0,
+                                              float dx1) {
+    if (p.coords) {
+        const float2 v = *reinterpret_cast<const float2*>(p.coords + ((long)b * N + i) * 2);
+        return v;
+    }
+    const float2 g = *reinterpret_cast<const float2*>(p.grid + (long)i * 2);
+    // x' = x @ [[c, s], [-s, c]]  (train_mnist.py:54-59), then + dx (train_mnist.py:70-74)
+    return make_float2(c * g.x - s * g.y + dx0, s * g.x + c * g.y + dx1);
+}
+
+__device__ __forceinline__ void image_pose(const PoseArgs& p, int b, float& c, float& s, float& dx0, float& dx1) {
+    c = 1.0f; s = 0.0f; dx0 = 0.0f; dx1 = 0.0f;
+    if (!p.coords) {
+        if (p.theta) {
+            const float t = p.theta[b];
+            c = cosf(t);
+            s = sinf(t);
+        }
+        if (p.dx) {
+            dx0 = p.dx[2 * b];
+            dx1 = p.dx[2 * b + 1];
+        }
+    }
+}
+
+// [x0, x1, x0^2, x1^2, x0*x1] (models.py:99-102); only the first in_dim entries are used
+__device__ __forceinline__ void coord_feats(float2 x, float f[5]) {
+    f[0] = x.x; f[1] = x.y; f[2] = x.x * x.x; f[3] = x.y * x.y; f[4] = x.x * x.y;
+}
+
+__device__ __forceinline__ float wave_sum32(float v) {  // sum over the 32 lanes of one half-wave
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) { return wave_sum32(v) + __shfl_xor(wave_sum32(v), 32); }
+
+// sum over a 256-thread block; result valid in every thread.  red must hold 4 floats.
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum32(v);
+    v += __shfl_xor(v, 32);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace svae

@@ -1,0 +1,499 @@
+// HBM-bound kernels around the MFMA GEMMs: weight packing, the per-image first-layer tables,
+// the coordinate layer (A1 + A2), the output layer (A4), the likelihoods (A5, A6) and the small
+// gradient reductions of A8.  All reductions are fixed-order (no atomics): results are bitwise
+// reproducible run to run.
+#pragma once
+#include "common.h"
+
+namespace svae {
+
+// ---------------------------------------------------------------- weight packing
+// W (H x H, row-major [n][k]) -> both contraction-octet-major images, zero-padded to Hp:
+//   wf[(k>>3)*Hp + n][k&7] : forward (contract over k, lane = n)
+//   wb[(n>>3)*Hp + k][n&7] : data gradient (contract over n, lane = k)
+__global__ void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ wf, float* __restrict__ wb, int H,
+                                    int Hp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Hp * Hp) return;
+    const int n = idx / Hp, k = idx % Hp;
+    const float v = (n < H && k < H) ? W[(long)n * H + k] : 0.0f;
+    wf[((long)(k >> 3) * Hp + n) * 8 + (k & 7)] = v;
+    wb[((long)(n >> 3) * Hp + k) * 8 + (n & 7)] = v;
+}
+
+// ---------------------------------------------------------------- per-image tables
+// tab[b][k][0..4] = W_c[k][p] + sum_q W_bi[k][p][q] z[b][q]      (models.py:104, 114-121)
+// tab[b][k][5]    = b_c[k]   + sum_q W_z[k][q]  z[b][q]          (models.py:104, 111-112)
+// posebuf[b]      = (cos t_b, sin t_b, dx0, dx1)                  (train_mnist.py:54-58, 70-71)
+__global__ void tables_kernel(const float* __restrict__ coord_w, const float* __restrict__ coord_b,
+                              const float* __restrict__ latent_w, const float* __restrict__ bil_w,
+                              const float* __restrict__ z, float* __restrict__ tab, float4* __restrict__ posebuf,
+                              PoseArgs pose, int B, int H, int Hp, int Zd, int in_dim) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < B) {
+        float c, s, d0, d1;
+        image_pose(pose, (int)idx, c, s, d0, d1);
+        posebuf[idx] = make_float4(c, s, d0, d1);
+    }
+    if (idx >= (long)B * Hp) return;
+    const int b = idx / Hp, k = idx % Hp;
+    float out[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k < H) {
+        for (int p = 0; p < in_dim; ++p) {
+            float w = coord_w[k * in_dim + p];
+            if (bil_w)
+                for (int q = 0; q < Zd; ++q) w += bil_w[((long)k * in_dim + p) * Zd + q] * z[(long)b * Zd + q];
+            out[p] = w;
+        }
+        float bias = coord_b[k];
+        if (latent_w)
+            for (int q = 0; q < Zd; ++q) bias += latent_w[(long)k * Zd + q] * z[(long)b * Zd + q];
+        out[kBiasSlot] = bias;
+    }
+    float4* dst = reinterpret_cast<float4*>(tab + idx * kSlots);
+    dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+}
+
+struct RowGeo {
+    int N, Npad, Hp, in_dim, act, B;
+};
+
+__device__ __forceinline__ float2 row_coord(const PoseArgs& pose, const float4 pb, int b, int i, int N) {
+    if (i >= N) return make_float2(0.0f, 0.0f);
+    return pixel_coord(pose, b, i, N, pb.x, pb.y, pb.z, pb.w);
+}
+
+// ---------------------------------------------------------------- coordinate layer, forward
+// a0[m][k] = act( sum_p feat_p(x''_m) tab[b][k][p] + tab[b][k][5] ): thread = (octet, k, half)
+// computes four consecutive rows and stores them as one 16-byte vector; the thread index IS the
+// output offset, so the 411 MB stream (BASELINE cfg 2) is written perfectly linearly.
+template <int ACT>
+__global__ void layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ posebuf, const float* __restrict__ tab,
+                                  float* __restrict__ a0, RowGeo g, long total) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int h = t & 1;
+    const long ok = t >> 1;
+    const int k = ok % g.Hp;
+    const long o = ok / g.Hp;
+    const long m0 = 8 * o + 4 * h;
+    const int b = m0 / g.Npad;
+    const int i0 = m0 % g.Npad;
+    const float4 pb = posebuf[b];
+    const float4* tp = reinterpret_cast<const float4*>(tab + ((long)b * g.Hp + k) * kSlots);
+    const float4 t0 = tp[0], t1 = tp[1];
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float2 x = row_coord(pose, pb, b, i0 + e, g.N);
+        float v = t1.y + x.x * t0.x + x.y * t0.y;
+        if (g.in_dim == 5) v += (x.x * x.x) * t0.z + (x.y * x.y) * t0.w + (x.x * x.y) * t1.x;
+        out[e] = act_fwd<ACT>(v);
+    }
+    *reinterpret_cast<float4*>(a0 + t * 4) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// ---------------------------------------------------------------- output layer, forward (A4)
+// logits[m][c] = sum_n a[m][n] W_o[c][n] + b_o[c]; y = sigmoid(logits) (+ softplus on channel 0).
+// One wave per row octet: lane (nl, h) walks the feature tiles with 16-byte loads (4 rows each)
+// and the 32 lanes of a half-wave are summed at the end.
+template <int C>
+__global__ void out_fwd_kernel(const float* __restrict__ a, const float* __restrict__ out_w,
+                               const float* __restrict__ out_b, float* __restrict__ y, float* __restrict__ logits,
+                               RowGeo g, int H, int softplus, long noct) {
+    const int lane = threadIdx.x & 63;
+    const int nl = lane & 31, h = lane >> 5;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    for (long o = wave0; o < noct; o += nwaves) {
+        float p[4][C];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[e][c] = 0.0f;
+        for (int t = 0; t < g.Hp / 32; ++t) {
+            const int n = t * 32 + nl;
+            const float4 v = *reinterpret_cast<const float4*>(a + ((o * g.Hp + n) * 8 + 4 * h));
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float w = (n < H) ? out_w[c * H + n] : 0.0f;
+                p[0][c] += v.x * w; p[1][c] += v.y * w; p[2][c] += v.z * w; p[3][c] += v.w * w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[e][c] = wave_sum32(p[e][c]);
+        if (nl < 4) {
+            const long m = 8 * o + 4 * h + nl;
+            const int b = m / g.Npad, i = m % g.Npad;
+            if (i < g.N) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float s0 = nl == 0 ? p[0][c] : nl == 1 ? p[1][c] : nl == 2 ? p[2][c] : p[3][c];
+                    const float lg = s0 + out_b[c];
+                    float s = 1.0f / (1.0f + expf(-lg));
+                    if (softplus && c == 0) s = log1pf(expf(s));
+                    const long oi = ((long)b * g.N + i) * C + c;
+                    y[oi] = s;
+                    if (logits) logits[oi] = lg;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- output layer, backward, step 1
+// do_p[c][mp] = dy * dy_scale[b] * (softplus') * s(1-s) on valid rows (pad rows stay 0 from the
+// memset), recomputing s from the logits exactly as the forward did.
+__global__ void dlogits_kernel(const float* __restrict__ logits, const float* __restrict__ dy,
+                               const float* __restrict__ dy_scale, float* __restrict__ do_p, int B, int N, int Npad,
+                               int C, int softplus, long Mp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * N * C) return;
+    const int c = idx % C;
+    const long bi = idx / C;
+    const int i = bi % N, b = bi / N;
+    const float lg = logits[idx];
+    const float s = 1.0f / (1.0f + expf(-lg));
+    float g = dy[idx];
+    if (dy_scale) g *= dy_scale[b];
+    if (softplus && c == 0) g *= 1.0f / (1.0f + expf(-s));
+    do_p[(long)c * Mp + (long)b * Npad + i] = g * s * (1.0f - s);
+}
+
+// ---------------------------------------------------------------- output layer, backward, step 2
+// dh[m][n] = (sum_c do[m][c] W_o[c][n]) * act'(a[m][n])  -> octet-major;  partial dW_o[c][n] per
+// row chunk.  Thread = fixed (n, half); it streams its column through the chunk's octets.
+template <int ACT, int C>
+__global__ void out_bwd_kernel(const float* __restrict__ a, const float* __restrict__ do_p,
+                               const float* __restrict__ out_w, float* __restrict__ dh, float* __restrict__ wpart,
+                               int H, int Hp, long Mp, long noct, long oct_per_chunk) {
+    const int t = blockIdx.x * 256 + threadIdx.x;  // over Hp*2
+    if (t >= Hp * 2) return;
+    const int h = t & 1, n = t >> 1;
+    float w[C], pw[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        w[c] = (n < H) ? out_w[c * H + n] : 0.0f;
+        pw[c] = 0.0f;
+    }
+    const long o0 = blockIdx.y * oct_per_chunk;
+    const long o1 = (o0 + oct_per_chunk < noct) ? o0 + oct_per_chunk : noct;
+    for (long o = o0; o < o1; ++o) {
+        const long off = (o * Hp + n) * 8 + 4 * h;
+        const float4 av = *reinterpret_cast<const float4*>(a + off);
+        float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 d = *reinterpret_cast<const float4*>(do_p + (long)c * Mp + 8 * o + 4 * h);
+            da.x += d.x * w[c]; da.y += d.y * w[c]; da.z += d.z * w[c]; da.w += d.w * w[c];
+            pw[c] += (d.x * av.x + d.y * av.y) + (d.z * av.z + d.w * av.w);
+        }
+        da.x *= act_grad<ACT>(av.x); da.y *= act_grad<ACT>(av.y);
+        da.z *= act_grad<ACT>(av.z); da.w *= act_grad<ACT>(av.w);
+        *reinterpret_cast<float4*>(dh + off) = da;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) wpart[(((long)blockIdx.y * 2 + h) * C + c) * Hp + n] = pw[c];
+}
+
+// dW_o[c][n] = sum over (chunk, half) of wpart; db_o[c] = sum_m do[m][c]
+__global__ void out_bwd_reduce_kernel(const float* __restrict__ wpart, const float* __restrict__ do_p,
+                                      float* __restrict__ dWo, float* __restrict__ dbo, int C, int H, int Hp,
+                                      int nparts, long Mp) {
+    __shared__ float red[4];
+    if (blockIdx.x < (unsigned)C) {  // one block per channel: bias gradient
+        const int c = blockIdx.x;
+        float s = 0.0f;
+        for (long m = threadIdx.x; m < Mp; m += 256) s += do_p[(long)c * Mp + m];
+        s = block_sum256(s, red);
+        if (threadIdx.x == 0 && dbo) dbo[c] = s;
+        return;
+    }
+    const long idx = (long)(blockIdx.x - C) * 256 + threadIdx.x;
+    if (idx >= (long)C * H || !dWo) return;
+    const int c = idx / H, n = idx % H;
+    float s = 0.0f;
+    for (int i = 0; i < nparts; ++i) s += wpart[((long)i * C + c) * Hp + n];
+    dWo[idx] = s;
+}
+
+// ---------------------------------------------------------------- coordinate layer, backward
+// (a) parameter side: per (image, chunk) partial sums over rows of dh0 and dh0 * feat_p:
+//     sg[part][k][half][0..4] = G[k][p], [5] = S[k].  Thread = fixed (k, half).
+__global__ void layer0_bwd_params_kernel(PoseArgs pose, const float4* __restrict__ posebuf,
+                                         const float* __restrict__ dh0, float* __restrict__ sgpart, RowGeo g,
+                                         int oct_per_chunk, int chunks_per_image) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Hp * 2) return;
+    const int h = t & 1, k = t >> 1;
+    const int b = blockIdx.y / chunks_per_image, ci = blockIdx.y % chunks_per_image;
+    const int oimg = g.Npad / 8;
+    const int oc0 = ci * oct_per_chunk;
+    const int oc1 = (oc0 + oct_per_chunk < oimg) ? oc0 + oct_per_chunk : oimg;
+    const float4 pb = posebuf[b];
+    float G[5] = {0, 0, 0, 0, 0};
+    float S = 0.0f;
+    for (int oc = oc0; oc < oc1; ++oc) {
+        const long o = (long)b * oimg + oc;
+        const float4 d = *reinterpret_cast<const float4*>(dh0 + (o * g.Hp + k) * 8 + 4 * h);
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const int i0 = oc * 8 + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 x = row_coord(pose, pb, b, i0 + e, g.N);
+            S += dv[e];
+            G[0] += dv[e] * x.x;
+            G[1] += dv[e] * x.y;
+            if (g.in_dim == 5) {
+                G[2] += dv[e] * x.x * x.x;
+                G[3] += dv[e] * x.y * x.y;
+                G[4] += dv[e] * x.x * x.y;
+            }
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(sgpart + (((long)blockIdx.y * g.Hp + k) * 2 + h) * kSlots);
+    dst[0] = make_float4(G[0], G[1], G[2], G[3]);
+    dst[1] = make_float4(G[4], S, 0.0f, 0.0f);
+}
+
+// sgimg[b][k][slot] = sum over (chunk, half) of sgpart
+__global__ void sg_reduce_kernel(const float* __restrict__ sgpart, float* __restrict__ sgimg, int B, int Hp,
+                                 int chunks_per_image) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*Hp*8
+    if (idx >= (long)B * Hp * kSlots) return;
+    const int slot = idx % kSlots;
+    const long bk = idx / kSlots;
+    const int k = bk % Hp, b = bk / Hp;
+    float s = 0.0f;
+    for (int ci = 0; ci < chunks_per_image; ++ci)
+        for (int h = 0; h < 2; ++h)
+            s += sgpart[((((long)b * chunks_per_image + ci) * Hp + k) * 2 + h) * kSlots + slot];
+    sgimg[idx] = s;
+}
+
+// (b) coordinate side: dfeat[m][p] = sum_k dh0[m][k] tab[b][k][p], chained through the feature
+//     expansion to d(coords).  One wave per row octet: lane = (row-in-octet, k mod 8).
+__global__ void layer0_bwd_coords_kernel(PoseArgs pose, const float4* __restrict__ posebuf,
+                                         const float* __restrict__ dh0, const float* __restrict__ tab,
+                                         float* __restrict__ dcoords, RowGeo g, long noct) {
+    const int lane = threadIdx.x & 63;
+    const int ml = lane & 7, kq = lane >> 3;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    for (long o = wave0; o < noct; o += nwaves) {
+        const long m = 8 * o + ml;
+        const int b = m / g.Npad, i = m % g.Npad;
+        float acc[5] = {0, 0, 0, 0, 0};
+        for (int k = kq; k < g.Hp; k += 8) {
+            const float d = dh0[(o * g.Hp + k) * 8 + ml];
+            const float4* tp = reinterpret_cast<const float4*>(tab + ((long)b * g.Hp + k) * kSlots);
+            const float4 t0 = tp[0];
+            acc[0] += d * t0.x;
+            acc[1] += d * t0.y;
+            if (g.in_dim == 5) {
+                const float4 t1 = tp[1];
+                acc[2] += d * t0.z;
+                acc[3] += d * t0.w;
+                acc[4] += d * t1.x;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            acc[p] += __shfl_xor(acc[p], 8);
+            acc[p] += __shfl_xor(acc[p], 16);
+            acc[p] += __shfl_xor(acc[p], 32);
+        }
+        if (kq == 0 && i < g.N) {
+            float d0 = acc[0], d1 = acc[1];
+            if (g.in_dim == 5) {
+                const float2 x = row_coord(pose, posebuf[b], b, i, g.N);
+                d0 += 2.0f * x.x * acc[2] + x.y * acc[4];
+                d1 += 2.0f * x.y * acc[3] + x.x * acc[4];
+            }
+            *reinterpret_cast<float2*>(dcoords + ((long)b * g.N + i) * 2) = make_float2(d0, d1);
+        }
+    }
+}
+
+// (c) first-layer parameter gradients from the per-image sums (one thread per feature k):
+//     dW_c[k][p] = sum_b G_b[k][p];  db_c[k] = sum_b S_b[k];  dW_z[k][q] = sum_b S_b[k] z[b][q];
+//     dW_bi[k][p][q] = sum_b G_b[k][p] z[b][q]
+__global__ void layer0_param_grads_kernel(const float* __restrict__ sgimg, const float* __restrict__ z,
+                                          float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWz,
+                                          float* __restrict__ dWbi, int B, int H, int Hp, int Zd, int in_dim) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= H) return;
+    float G[5] = {0, 0, 0, 0, 0};
+    float S = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* e = sgimg + ((long)b * Hp + k) * kSlots;
+        for (int p = 0; p < in_dim; ++p) G[p] += e[p];
+        S += e[kBiasSlot];
+    }
+    if (dWc)
+        for (int p = 0; p < in_dim; ++p) dWc[k * in_dim + p] = G[p];
+    if (dbc) dbc[k] = S;
+    if (dWz)
+        for (int q = 0; q < Zd; ++q) {
+            float s = 0.0f;
+            for (int b = 0; b < B; ++b) s += sgimg[((long)b * Hp + k) * kSlots + kBiasSlot] * z[(long)b * Zd + q];
+            dWz[(long)k * Zd + q] = s;
+        }
+    if (dWbi)
+        for (int p = 0; p < in_dim; ++p)
+            for (int q = 0; q < Zd; ++q) {
+                float s = 0.0f;
+                for (int b = 0; b < B; ++b) s += sgimg[((long)b * Hp + k) * kSlots + p] * z[(long)b * Zd + q];
+                dWbi[((long)k * in_dim + p) * Zd + q] = s;
+            }
+}
+
+// (d) dz[b][q] = sum_k S_b[k] W_z[k][q] + sum_{k,p} G_b[k][p] W_bi[k][p][q]   (one block per image)
+__global__ void dz_kernel(const float* __restrict__ sgimg, const float* __restrict__ latent_w,
+                          const float* __restrict__ bil_w, float* __restrict__ dz, int H, int Hp, int Zd, int in_dim) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    for (int q = 0; q < Zd; ++q) {
+        float s = 0.0f;
+        for (int k = threadIdx.x; k < H; k += 256) {
+            const float* e = sgimg + ((long)b * Hp + k) * kSlots;
+            s += e[kBiasSlot] * latent_w[(long)k * Zd + q];
+            if (bil_w)
+                for (int p = 0; p < in_dim; ++p) s += e[p] * bil_w[((long)k * in_dim + p) * Zd + q];
+        }
+        s = block_sum256(s, red);
+        if (threadIdx.x == 0) dz[(long)b * Zd + q] = s;
+    }
+}
+
+// (e) pose gradients from d(coords) (one block per image):
+//     dtheta[b] = sum_i dx0 (-s g0 - c g1) + dx1 (c g0 - s g1);  ddx[b] = sum_i dcoords[b,i]
+__global__ void pose_bwd_kernel(const float* __restrict__ dcoords, const float* __restrict__ grid,
+                                const float4* __restrict__ posebuf, float* __restrict__ dtheta,
+                                float* __restrict__ ddx, int N) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float4 pb = posebuf[b];
+    float st = 0.0f, s0 = 0.0f, s1 = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float2 d = *reinterpret_cast<const float2*>(dcoords + ((long)b * N + i) * 2);
+        const float2 gr = *reinterpret_cast<const float2*>(grid + (long)i * 2);
+        st += d.x * (-pb.y * gr.x - pb.x * gr.y) + d.y * (pb.x * gr.x - pb.y * gr.y);
+        s0 += d.x;
+        s1 += d.y;
+    }
+    st = block_sum256(st, red);
+    s0 = block_sum256(s0, red);
+    s1 = block_sum256(s1, red);
+    if (threadIdx.x == 0) {
+        if (dtheta) dtheta[b] = st;
+        if (ddx) {
+            ddx[2 * b] = s0;
+            ddx[2 * b + 1] = s1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- A5: Bernoulli log-likelihood
+// loglik[b] = sum_j t log(s) + (1-t) log(1-s), both logs clamped at -100 (torch's
+// binary_cross_entropy), dll = -(s-t)/max((1-s)s, 1e-12).  One block per image.
+__global__ void bce_kernel(const float* __restrict__ y_hat, const float* __restrict__ target,
+                           float* __restrict__ loglik, float* __restrict__ dll, int n) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float acc = 0.0f;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const long idx = (long)b * n + j;
+        const float s = y_hat[idx], t = target[idx];
+        const float ls = fmaxf(logf(s), -100.0f);
+        const float l1s = fmaxf(log1pf(-s), -100.0f);
+        acc += t * ls + (1.0f - t) * l1s;
+        if (dll) dll[idx] = -(s - t) / fmaxf((1.0f - s) * s, 1e-12f);
+    }
+    acc = block_sum256(acc, red);
+    if (threadIdx.x == 0) loglik[b] = acc;
+}
+
+// ---------------------------------------------------------------- A5/A6: Gaussian log-likelihood
+// One block per image.  Follows train_particles.py:102-139 including the channel-interleave quirk
+// (mean = first N entries of the (N*C)-long row, log-variance = last N), the CTF cross-correlation
+// of the mean image (zero padding k/2) and the pixel mask.  filt/dflt: (B, N) scratch for the
+// filtered mean and the gradient flowing back into the filter's output.
+__global__ void gaussian_kernel(const float* __restrict__ yp, const float* __restrict__ target,
+                                const uint8_t* __restrict__ mask, const float* __restrict__ ctf, int k,
+                                float* __restrict__ loglik, float* __restrict__ dll, float* __restrict__ filt,
+                                float* __restrict__ dflt, int N, int C) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int n = (int)(sqrtf((float)N) + 0.5f);
+    const float* row = yp + (long)b * N * C;
+    const bool noise = C > 1;
+    const int pad = k / 2;
+    const float* f = ctf ? ctf + (long)b * k * k : nullptr;
+    if (ctf) {
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const int r = j / n, cidx = j % n;
+            float s = 0.0f;
+            for (int u = 0; u < k; ++u) {
+                const int rr = r + u - pad;
+                if (rr < 0 || rr >= n) continue;
+                for (int v = 0; v < k; ++v) {
+                    const int cc = cidx + v - pad;
+                    if (cc < 0 || cc >= n) continue;
+                    s += row[rr * n + cc] * f[u * k + v];
+                }
+            }
+            filt[(long)b * N + j] = s;
+        }
+        __syncthreads();
+    }
+    float acc = 0.0f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const bool on = mask ? mask[j] != 0 : true;
+        const float mu = ctf ? filt[(long)b * N + j] : row[j];
+        const float diff = mu - target[(long)b * N + j];
+        float dmu = 0.0f, dlv = 0.0f;
+        if (on) {
+            if (noise) {
+                const float lv = row[N + j];
+                const float iv = expf(-lv);
+                acc += -0.5f * (diff * diff / expf(lv) + lv);
+                dmu = -diff / expf(lv);
+                dlv = -0.5f * (1.0f - diff * diff * iv);
+            } else {
+                acc += -0.5f * diff * diff;
+                dmu = -diff;
+            }
+        }
+        if (dll) {
+            if (ctf) dflt[(long)b * N + j] = dmu;
+            else dll[(long)b * N * C + j] = dmu;
+            if (noise) dll[(long)b * N * C + N + j] = dlv;
+        }
+    }
+    acc = block_sum256(acc, red);
+    if (threadIdx.x == 0) loglik[b] = acc;
+    if (ctf && dll) {
+        __syncthreads();
+        // adjoint of the cross-correlation: dimg[r'][c'] = sum_{u,v} d[r'-u+pad][c'-v+pad] f[u][v]
+        for (int j = threadIdx.x; j < N; j += 256) {
+            const int r = j / n, cidx = j % n;
+            float s = 0.0f;
+            for (int u = 0; u < k; ++u) {
+                const int rr = r - u + pad;
+                if (rr < 0 || rr >= n) continue;
+                for (int v = 0; v < k; ++v) {
+                    const int cc = cidx - v + pad;
+                    if (cc < 0 || cc >= n) continue;
+                    s += dflt[(long)b * N + rr * n + cc] * f[u * k + v];
+                }
+            }
+            dll[(long)b * N * C + j] = s;
+        }
+    }
+}
+
+}  // namespace svae

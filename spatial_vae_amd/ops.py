@@ -1,0 +1,220 @@
+"""torch.autograd plumbing around the C-ABI (include/svae.h).
+
+PyTorch is used here for device memory, the current HIP stream and the autograd graph only; all
+arithmetic of the decoder path happens in the HIP library.  There is deliberately NO fallback:
+CPU tensors or a missing library raise.
+"""
+import ctypes
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+
+DecoderSpec = namedtuple("DecoderSpec", "latent_dim hidden_dim n_out num_layers act softplus resid expand_coords bilinear")
+
+_ws_cache = {}
+
+
+def _require_hip(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("spatial_vae_amd: %s must live on a HIP device (got %s); the MI355X path has no CPU "
+                           "fallback" % (what, t.device))
+
+
+def _buf(device, nbytes, key):
+    """Grow-only byte buffer per (device, key); 256-byte aligned by the caching allocator."""
+    k = (device, key)
+    t = _ws_cache.get(k)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[k] = t
+    return t
+
+
+def _f32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_desc(spec, B, N):
+    d = _lib.Desc()
+    d.B, d.N, d.H, d.L = int(B), int(N), int(spec.hidden_dim), int(spec.num_layers)
+    d.Zd, d.C = int(spec.latent_dim), int(spec.n_out)
+    d.in_dim = 5 if spec.expand_coords else 2
+    d.act = _lib.ACT[spec.act]
+    bil = bool(spec.bilinear) and spec.latent_dim > 0
+    d.flags = (_lib.FLAG_RESID if spec.resid else 0) | (_lib.FLAG_BILINEAR if bil else 0) | \
+              (_lib.FLAG_SOFTPLUS if spec.softplus else 0)
+    return d
+
+
+def _fill_params(struct, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden):
+    struct.coord_w, struct.coord_b = _p(coord_w), _p(coord_b)
+    struct.latent_w, struct.bilinear_w = _p(latent_w), _p(bilinear_w)
+    struct.out_w, struct.out_b = _p(out_w), _p(out_b)
+    for l in range(len(hidden) // 2):
+        struct.hidden_w[l] = _p(hidden[2 * l])
+        struct.hidden_b[l] = _p(hidden[2 * l + 1])
+    return struct
+
+
+class _Decoder(torch.autograd.Function):
+    """y, logits = decoder(coords | grid+theta+dx, z; parameters)   (svae_decoder_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden):
+        L = _lib.lib()
+        ref = coords if coords is not None else grid
+        _require_hip(ref, "coordinates")
+        device = ref.device
+        coords, grid, theta, dx, z = _f32(coords), _f32(grid), _f32(theta), _f32(dx), _f32(z)
+        coord_w, coord_b, latent_w, bilinear_w = _f32(coord_w), _f32(coord_b), _f32(latent_w), _f32(bilinear_w)
+        out_w, out_b = _f32(out_w), _f32(out_b)
+        hidden = tuple(_f32(h) for h in hidden)
+        for t in (z, coord_w, out_w) + hidden:
+            if t is not None:
+                _require_hip(t, "decoder inputs and parameters")
+        N = coords.shape[1] if coords is not None else grid.shape[0]
+        if len(hidden) != 2 * (spec.num_layers - 1):
+            raise RuntimeError("expected %d hidden tensors, got %d" % (2 * (spec.num_layers - 1), len(hidden)))
+        if spec.latent_dim > 0 and (z is None or tuple(z.shape) != (B, spec.latent_dim)):
+            raise RuntimeError("z must be (%d, %d), got %s" % (B, spec.latent_dim, None if z is None else tuple(z.shape)))
+        desc = make_desc(spec, B, N)
+        params = _fill_params(_lib.Params(), coord_w, coord_b, latent_w if spec.latent_dim > 0 else None,
+                              bilinear_w if (desc.flags & _lib.FLAG_BILINEAR) else None, out_w, out_b, hidden)
+        pose = _lib.Pose()
+        pose.coords, pose.grid, pose.theta, pose.dx = _p(coords), _p(grid), _p(theta), _p(dx)
+        need_grad = any(ctx.needs_input_grad)
+        ws_bytes = L.svae_workspace_bytes(ctypes.byref(desc))
+        ws = _buf(device, ws_bytes, "ws")
+        saved = None
+        if need_grad:
+            saved = torch.empty(max(L.svae_saved_bytes(ctypes.byref(desc)), 256), dtype=torch.uint8, device=device)
+        y = torch.empty((B, N, spec.n_out), dtype=torch.float32, device=device)
+        logits = torch.empty_like(y)
+        with torch.cuda.device(device):
+            _lib.check(L.svae_decoder_forward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
+                                              y.data_ptr(), logits.data_ptr(), _p(saved), ws.data_ptr(), ws.numel(),
+                                              _stream(device)))
+        ctx.spec, ctx.B, ctx.N = spec, B, N
+        ctx.saved_buf = saved
+        ctx.tensors = (coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits)
+        ctx.mark_non_differentiable(logits)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, dy, _dlogits):
+        L = _lib.lib()
+        spec, B, N = ctx.spec, ctx.B, ctx.N
+        coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits = ctx.tensors
+        device = logits.device
+        dy = _f32(dy)
+        desc = make_desc(spec, B, N)
+        bil = bool(desc.flags & _lib.FLAG_BILINEAR)
+        params = _fill_params(_lib.Params(), coord_w, coord_b, latent_w if spec.latent_dim > 0 else None,
+                              bilinear_w if bil else None, out_w, out_b, hidden)
+        pose = _lib.Pose()
+        pose.coords, pose.grid, pose.theta, pose.dx = _p(coords), _p(grid), _p(theta), _p(dx)
+        ng = ctx.needs_input_grad  # (spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden)
+
+        def new(t, want):
+            return torch.empty_like(t) if (t is not None and want) else None
+
+        g_coords, g_theta, g_dx, g_z = new(coords, ng[2]), new(theta, ng[4]), new(dx, ng[5]), new(z, ng[6] and spec.latent_dim > 0)
+        g_cw, g_cb = new(coord_w, ng[7]), new(coord_b, ng[8])
+        g_lw = new(latent_w, ng[9] and spec.latent_dim > 0)
+        g_bw = new(bilinear_w, ng[10] and bil)
+        g_ow, g_ob = new(out_w, ng[11]), new(out_b, ng[12])
+        g_hidden = tuple(new(h, ng[13 + i]) for i, h in enumerate(hidden))
+        grads = _fill_params(_lib.Params(), g_cw, g_cb, g_lw, g_bw, g_ow, g_ob, g_hidden)
+        pg = _lib.PoseGrads()
+        pg.dcoords, pg.dtheta, pg.ddx = _p(g_coords), _p(g_theta), _p(g_dx)
+        ws_bytes = L.svae_workspace_bytes(ctypes.byref(desc))
+        ws = _buf(device, ws_bytes, "ws")
+        with torch.cuda.device(device):
+            _lib.check(L.svae_decoder_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
+                                               logits.data_ptr(), dy.data_ptr(), None, ctx.saved_buf.data_ptr(),
+                                               ctypes.byref(grads), _p(g_z), ctypes.byref(pg), ws.data_ptr(), ws.numel(),
+                                               _stream(device)))
+        ctx.saved_buf = None
+        return (None, None, g_coords, None, g_theta, g_dx, g_z, g_cw, g_cb, g_lw, g_bw, g_ow, g_ob) + g_hidden
+
+
+def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden):
+    """Returns (y, logits), each (B, N, n_out).  Exactly one of coords / grid is given."""
+    return _Decoder.apply(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b,
+                          *hidden)
+
+
+class _BceLoglik(torch.autograd.Function):
+    """loglik[b] = -sum_j bce(y_hat[b, j], target[b, j])  (svae_bce_loglik)."""
+
+    @staticmethod
+    def forward(ctx, y_hat, target):
+        L = _lib.lib()
+        _require_hip(y_hat, "y_hat")
+        y_hat, target = _f32(y_hat), _f32(target)
+        B = y_hat.shape[0]
+        n = y_hat.numel() // B
+        if target.numel() != y_hat.numel():
+            raise RuntimeError("target shape %s does not match y_hat %s" % (tuple(target.shape), tuple(y_hat.shape)))
+        loglik = torch.empty(B, dtype=torch.float32, device=y_hat.device)
+        dll = torch.empty_like(y_hat) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(y_hat.device):
+            _lib.check(L.svae_bce_loglik(B, n, y_hat.data_ptr(), target.data_ptr(), loglik.data_ptr(), _p(dll),
+                                         _stream(y_hat.device)))
+        ctx.dll = dll
+        return loglik
+
+    @staticmethod
+    def backward(ctx, g):
+        dll = ctx.dll
+        return dll * g.reshape((-1,) + (1,) * (dll.dim() - 1)), None
+
+
+def bce_loglik(y_hat, target):
+    return _BceLoglik.apply(y_hat, target)
+
+
+class _GaussianLoglik(torch.autograd.Function):
+    """Per-image Gaussian log-likelihood of train_particles.py:102-139 (svae_gaussian_loglik)."""
+
+    @staticmethod
+    def forward(ctx, y_params, target, mask, ctf):
+        L = _lib.lib()
+        _require_hip(y_params, "y_params")
+        y_params, target, ctf = _f32(y_params), _f32(target), _f32(ctf)
+        B, N = target.shape
+        C = y_params.shape[1] // N
+        if mask is not None:
+            mask = mask.to(device=y_params.device, dtype=torch.uint8).contiguous()
+        k = 0 if ctf is None else int(ctf.shape[-1])
+        ws_bytes = L.svae_gaussian_workspace_bytes(B, N) if ctf is not None else 0
+        ws = _buf(y_params.device, ws_bytes, "gauss") if ws_bytes else None
+        loglik = torch.empty(B, dtype=torch.float32, device=y_params.device)
+        dll = torch.zeros_like(y_params) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(y_params.device):
+            _lib.check(L.svae_gaussian_loglik(B, N, C, y_params.data_ptr(), target.data_ptr(), _p(mask), _p(ctf), k,
+                                              loglik.data_ptr(), _p(dll), _p(ws), ws_bytes, _stream(y_params.device)))
+        ctx.dll = dll
+        return loglik
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.dll * g[:, None], None, None, None
+
+
+def gaussian_loglik(y_params, target, mask=None, ctf=None):
+    return _GaussianLoglik.apply(y_params, target, mask, ctf)
