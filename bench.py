@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the spatial-VAE ELBO training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + backward + Adam step of the ELBO on one minibatch per GPU
+(train_mnist.py:143-150 of the reference), on BASELINE.json configs[1]: rotated+translated MNIST
+shape 28x28, z=2, p/q hidden 500 x 2 layers, tanh, batch 256 PER GPU (weak scaling: the global
+batch is 256*N, sharded as spatial_vae_amd/dp.py describes, one RCCL all-reduce of the flat
+gradient per step).  Inputs are synthetic (there are no datasets here) and resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     : the dominant kernel (an fp32-MFMA GEMM of the decoder's 500x500 layer) --
+                 algorithmic FLOPs per launch / its average launch duration, the durations taken
+                 live from HIP events recorded on the launch stream during the timed steps
+                 (svae_profile_* in include/svae.h); peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline : the torch-CPU restatement of the reference's step (oracle/torch_cpu_step.py),
+                 timed on this box's host cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import contextlib
+import io
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+CFG = dict(name="mnist-rotated-translated 28x28 z=2 H=500x2 tanh B=256/GPU (BASELINE configs[1])",
+           n=28, m=28, B=256, z_dim=2, H=500, L=2, q_hidden=500, q_layers=2, dx_scale=0.1, theta_prior=math.pi / 4,
+           lr=1e-4)
+
+
+def synthetic_batch(rs, B, N):
+    """MNIST-like sparse uniform targets, uint8-quantised /255."""
+    u = rs.uniform(size=(B, N))
+    keep = rs.uniform(size=(B, N)) > 0.8
+    return (np.floor(u * keep * 255.0) / 255.0).astype(np.float32)
+
+
+def coord_grid(n, m):
+    x0, x1 = np.meshgrid(np.linspace(-1, 1, m), np.linspace(1, -1, n))
+    return np.stack([x0.ravel(), x1.ravel()], 1).astype(np.float32)
+
+
+def build_nets(cfg):
+    import spatial_vae.models as models
+    torch.manual_seed(0)  # p_net before q_net, default nn.Linear init (train_mnist.py:370-375)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p_net = models.SpatialGenerator(cfg["z_dim"], cfg["H"], n_out=1, num_layers=cfg["L"], activation=nn.Tanh)
+        q_net = models.InferenceNetwork(cfg["n"] * cfg["m"], cfg["z_dim"] + 3, cfg["q_hidden"],
+                                        num_layers=cfg["q_layers"], activation=nn.Tanh)
+    return p_net, q_net
+
+
+def decoder_flops(cfg):
+    M = cfg["B"] * cfg["n"] * cfg["m"]
+    H = cfg["H"]
+    fwd = 2.0 * M * (2 * H + (cfg["L"] - 1) * H * H + H * 1) + 2.0 * cfg["B"] * cfg["z_dim"] * H
+    return fwd, 3.0 * fwd, 2.0 * M * H * H
+
+
+def cpu_baseline(cfg, seconds):
+    """Time the torch-CPU restatement of the reference step on the host cores."""
+    from oracle import torch_cpu_step as T
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p_net, q_net = build_nets(cfg)
+    rs = np.random.RandomState(123)
+    N = cfg["n"] * cfg["m"]
+    tr = T.CpuTrainer({k: v.detach().numpy() for k, v in p_net.state_dict().items()},
+                      {k: v.detach().numpy() for k, v in q_net.state_dict().items()}, coord_grid(cfg["n"], cfg["m"]),
+                      lr=cfg["lr"], act="tanh", rotate=True, translate=True, dx_scale=cfg["dx_scale"],
+                      theta_prior=cfg["theta_prior"])
+    y = torch.from_numpy(synthetic_batch(rs, cfg["B"], N))
+    r = torch.randn(cfg["B"], cfg["z_dim"] + 3)
+    tr.step(y, r)  # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 3 or (time.perf_counter() - t0 < seconds and steps < 50):
+        tr.step(y, r)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": cfg["B"] * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d full steps (fwd+bwd+Adam) at batch %d after 1 warm-up, %.1f s, torch %s CPU, %d threads"
+                      % (steps, cfg["B"], dt, torch.__version__, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    from spatial_vae_amd import _lib, dp
+    from spatial_vae_amd import elbo as E
+
+    rank, world, local = dp.init_process_group(device_is_gpu=True)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg = dict(CFG)
+    N = cfg["n"] * cfg["m"]
+
+    p_net, q_net = build_nets(cfg)
+    p_net.to(dev)
+    q_net.to(dev)
+    step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=cfg["lr"], rotate=True, translate=True,
+                        dx_scale=cfg["dx_scale"], theta_prior=cfg["theta_prior"])
+    x = torch.from_numpy(coord_grid(cfg["n"], cfg["m"])).to(dev)
+    rs = np.random.RandomState(1000 + rank)
+    pool = [torch.from_numpy(synthetic_batch(rs, cfg["B"], N)).to(dev) for _ in range(4)]
+
+    def run(k):
+        for i in range(k):
+            step(x, pool[i % len(pool)])
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    profile = not args.no_profile
+    if profile:
+        _lib.profile_enable(True)
+        _lib.profile_read()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_read() if profile else {}
+    _lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        f_fwd, f_step, f_gemm = decoder_flops(cfg)
+        ms = 1e3 * elapsed / args.steps
+        gemm = {k: prof[k] for k in ("dense_fwd", "dense_dgrad", "wgrad") if k in prof}
+        roofline = None
+        if gemm:
+            dom = max(gemm, key=lambda k: gemm[k][0])
+            avg_ms = gemm[dom][0] / gemm[dom][1]
+            ach = f_gemm / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": f_gemm,
+                        "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}}
+        out = {"metric": "images/sec (ELBO fwd+bwd+step), MNIST 28x28 batch=256, 1/2/4/8 GPU",
+               "value": round(cfg["B"] * world * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg["name"], "global_batch": cfg["B"] * world, "per_gpu_batch": cfg["B"],
+                          "pixels": N, "parallelism": "dp%d" % world,
+                          "decoder_step_gflop_per_gpu": round(f_step / 1e9, 1),
+                          "decoder_mfma_frac_of_step": round(f_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

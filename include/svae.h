@@ -169,6 +169,18 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
                          const uint8_t* mask, const float* ctf, int32_t k, float* loglik, float* dll_dy,
                          void* ws, size_t ws_bytes, svae_stream_t stream);
 
+/*
+ * Optional per-kernel timing (bench.py's roofline figure).  While enabled, every kernel launch of
+ * this library is bracketed by two HIP events recorded on the launch stream; svae_profile_read
+ * synchronises those events and returns, per kernel kind, the summed device time in ms and the
+ * number of launches, then clears the records.  Not for use under stream capture.  The reference
+ * has no counterpart (it has no profiling at all: SURVEY.md section 5).
+ */
+#define SVAE_PROF_KINDS 16
+int svae_profile_enable(int on);
+int svae_profile_read(double* ms_total, int64_t* launches); /* arrays of SVAE_PROF_KINDS */
+const char* svae_profile_kind_name(int kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,9 @@ FLAG_RESID, FLAG_BILINEAR, FLAG_SOFTPLUS = 1, 2, 4
 
 EXPORTS = ("svae_abi_version", "svae_last_error", "svae_saved_bytes", "svae_workspace_bytes",
            "svae_decoder_forward", "svae_decoder_backward", "svae_bce_loglik",
-           "svae_gaussian_workspace_bytes", "svae_gaussian_loglik")
+           "svae_gaussian_workspace_bytes", "svae_gaussian_loglik", "svae_profile_enable", "svae_profile_read",
+           "svae_profile_kind_name")
+PROF_KINDS = 16
 
 
 class Desc(ctypes.Structure):
@@ -70,6 +72,12 @@ def lib():
     L.svae_gaussian_workspace_bytes.argtypes = [i32, i32]
     L.svae_gaussian_loglik.restype = ctypes.c_int
     L.svae_gaussian_loglik.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]
+    L.svae_profile_enable.restype = ctypes.c_int
+    L.svae_profile_enable.argtypes = [ctypes.c_int]
+    L.svae_profile_read.restype = ctypes.c_int
+    L.svae_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+    L.svae_profile_kind_name.restype = ctypes.c_char_p
+    L.svae_profile_kind_name.argtypes = [ctypes.c_int]
     if L.svae_abi_version() != 1:
         raise RuntimeError("spatial_vae_amd: ABI version mismatch")
     _lib = L
@@ -79,3 +87,16 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("svae: %s (code %d)" % (lib().svae_last_error().decode(), rc))
+
+
+def profile_enable(on):
+    check(lib().svae_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """{kernel kind: (total ms, launches)} since the last read; synchronises the recorded events."""
+    L = lib()
+    ms = (ctypes.c_double * PROF_KINDS)()
+    cnt = (ctypes.c_int64 * PROF_KINDS)()
+    check(L.svae_profile_read(ms, cnt))
+    return {L.svae_profile_kind_name(k).decode(): (ms[k], cnt[k]) for k in range(PROF_KINDS) if cnt[k]}

@@ -2,7 +2,10 @@
 // planning and the kernel launch sequences.  Nothing here allocates or synchronises.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "dense.h"
@@ -150,6 +153,42 @@ int check_ws(const Plan& p, const void* ws, size_t ws_bytes) {
     return SVAE_OK;
 }
 
+// ---- opt-in per-kernel timing with HIP events (svae_profile_*)
+enum Kind { K_PREPARE = 0, K_LAYER0_FWD, K_DENSE_FWD, K_OUT_FWD, K_DLOGITS, K_OUT_BWD, K_WGRAD, K_WGRAD_REDUCE,
+            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_COUNT };
+const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense_fwd", "out_fwd", "dlogits", "out_bwd",
+                                                 "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
+                                                 "gaussian", "", "", ""};
+struct ProfRec { hipEvent_t a, b; int kind; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_used, g_prof_free;
+
+struct Scope {  // brackets the launches issued during its lifetime
+    hipStream_t st;
+    ProfRec rec;
+    bool on;
+    Scope(int kind, hipStream_t s) : st(s), on(false) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_on) return;
+        if (!g_prof_free.empty()) {
+            rec = g_prof_free.back();
+            g_prof_free.pop_back();
+        } else if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) {
+            return;
+        }
+        rec.kind = kind;
+        on = true;
+        (void)hipEventRecord(rec.a, st);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(rec.b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_used.push_back(rec);
+    }
+};
+
 int launch_status(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SVAE_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -175,6 +214,7 @@ RowGeo row_geo(const Geo& g) {
 
 // tables + packed weights: needed by both directions, rebuilt per call (a few MB of traffic)
 void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const PoseArgs& pa, const float* z, hipStream_t st) {
+    Scope prof(K_PREPARE, st);
     const long nt = (long)g.B * g.Hp;
     hipLaunchKernelGGL(tables_kernel, dim3(blocks_for(nt > g.B ? nt : g.B)), dim3(256), 0, st, p->coord_w, p->coord_b,
                        g.Zd > 0 ? p->latent_w : nullptr, (g.flags & SVAE_FLAG_BILINEAR) ? p->bilinear_w : nullptr, z,
@@ -184,24 +224,51 @@ void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const Po
                            pl.wf[l], pl.wb[l], g.H, g.Hp);
 }
 
+template <int NT, bool DGRAD, bool RESID>
+void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;  // LDS beyond 64 KiB needs the opt-in attribute once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, DenseCfg<NT>::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID>), grid, dim3(256), DenseCfg<NT>::LDS_BYTES, st, a);
+}
+
+template <int NT, bool DGRAD>
+void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st) {
+    if (a.resid) launch_dense_ntr<NT, DGRAD, true>(a, grid, st);
+    else launch_dense_ntr<NT, DGRAD, false>(a, grid, st);
+}
+
+// column tiles accumulated per pass: the widest that divides the layer, unless SVAE_DENSE_NT caps it
+int dense_nt_for(int ntile) {
+    static const int cap = [] {
+        const char* e = getenv("SVAE_DENSE_NT");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 8;
+    }();
+    int nt = 16;
+    while (nt > 1 && (ntile % nt != 0 || nt > cap)) nt >>= 1;
+    return nt;
+}
+
 template <bool DGRAD>
 void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st) {
-    const dim3 grid((unsigned)((g.tiles + 3) / 4)), block(256);
-    if (g.ntile % 16 == 0) {
-        hipLaunchKernelGGL((dense_kernel<16, DGRAD>), grid, block, 2 * 2 * 512 * 8 * 4, st, a);
-    } else if (g.ntile % 8 == 0) {
-        hipLaunchKernelGGL((dense_kernel<8, DGRAD>), grid, block, 2 * 4 * 256 * 8 * 4, st, a);
-    } else if (g.ntile % 4 == 0) {
-        hipLaunchKernelGGL((dense_kernel<4, DGRAD>), grid, block, 2 * 4 * 128 * 8 * 4, st, a);
-    } else if (g.ntile % 2 == 0) {
-        hipLaunchKernelGGL((dense_kernel<2, DGRAD>), grid, block, 2 * 4 * 64 * 8 * 4, st, a);
-    } else {
-        hipLaunchKernelGGL((dense_kernel<1, DGRAD>), grid, block, 2 * 4 * 32 * 8 * 4, st, a);
+    Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
+    const dim3 grid((unsigned)((g.tiles + 3) / 4));
+    switch (dense_nt_for(g.ntile)) {
+        case 16: launch_dense_nt<16, DGRAD>(a, grid, st); break;
+        case 8: launch_dense_nt<8, DGRAD>(a, grid, st); break;
+        case 4: launch_dense_nt<4, DGRAD>(a, grid, st); break;
+        case 2: launch_dense_nt<2, DGRAD>(a, grid, st); break;
+        default: launch_dense_nt<1, DGRAD>(a, grid, st); break;
     }
 }
 
 template <int ACT>
 void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
+    Scope prof(K_LAYER0_FWD, st);
     const long total = g.noct * g.Hp * 2;
     hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(total)), dim3(256), 0, st, pa, pl.posebuf, pl.tab, a0,
                        row_geo(g), total);
@@ -209,6 +276,7 @@ void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* 
 
 template <int C>
 void launch_out_fwd(const Geo& g, const float* a, const svae_params* p, float* y, float* logits, hipStream_t st) {
+    Scope prof(K_OUT_FWD, st);
     long nb = (g.noct + 3) / 4;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL((out_fwd_kernel<C>), dim3((unsigned)nb), dim3(256), 0, st, a, p->out_w, p->out_b, y, logits,
@@ -217,6 +285,7 @@ void launch_out_fwd(const Geo& g, const float* a, const svae_params* p, float* y
 
 template <int ACT, int C>
 void launch_out_bwd_ac(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh, hipStream_t st) {
+    Scope prof(K_OUT_BWD, st);
     hipLaunchKernelGGL((out_bwd_kernel<ACT, C>), dim3(blocks_for(g.Hp * 2), pl.ob_chunks), dim3(256), 0, st, a, pl.do_p,
                        p->out_w, dh, pl.wpart, g.H, g.Hp, (long)g.Mp, g.noct, pl.ob_oct_per_chunk);
 }
@@ -312,10 +381,13 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     launch_prepare(g, pl, p, pa, z, st);
 
     // d(loss)/d(logits) in padded row space (pad rows exactly zero)
-    if (hipMemsetAsync(pl.do_p, 0, (size_t)g.C * g.Mp * sizeof(float), st) != hipSuccess)
-        return fail(SVAE_E_LAUNCH, "memset failed");
-    hipLaunchKernelGGL(dlogits_kernel, dim3(blocks_for((long)g.B * g.N * g.C)), dim3(256), 0, st, logits, dy, dy_scale,
-                       pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
+    {
+        Scope prof(K_DLOGITS, st);
+        if (hipMemsetAsync(pl.do_p, 0, (size_t)g.C * g.Mp * sizeof(float), st) != hipSuccess)
+            return fail(SVAE_E_LAUNCH, "memset failed");
+        hipLaunchKernelGGL(dlogits_kernel, dim3(blocks_for((long)g.B * g.N * g.C)), dim3(256), 0, st, logits, dy, dy_scale,
+                           pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
+    }
 
     // output layer: dh_{L-1}, dW_o, db_o
     int cur = 0;
@@ -326,8 +398,11 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         case SVAE_ACT_RELU: launch_out_bwd_a<SVAE_ACT_RELU>(g, pl, alast, p, pl.dh[cur], st); break;
         default: launch_out_bwd_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, pl.dh[cur], st); break;
     }
-    hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C + blocks_for((long)g.C * g.H)), dim3(256), 0, st, pl.wpart, pl.do_p,
-                       grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2, (long)g.Mp);
+    {
+        Scope prof(K_SMALL_BWD, st);
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C + blocks_for((long)g.C * g.H)), dim3(256), 0, st, pl.wpart,
+                           pl.do_p, grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2, (long)g.Mp);
+    }
 
     // hidden layers, last to first
     for (int l = g.L - 1; l >= 1; --l) {
@@ -340,7 +415,17 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             w.noct = g.noct;
             w.Hp = g.Hp;
             w.nblk1 = pl.wg_nblk1;
-            hipLaunchKernelGGL(wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), 0, st, w);
+            {
+                Scope prof(K_WGRAD, st);
+                static bool attr_set = false;  // 128 KiB of LDS (4 waves x 4 slots x 8 KiB) needs the opt-in
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLdsBytes);
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), kWgradLdsBytes, st, w);
+            }
+            Scope prof(K_WGRAD_REDUCE, st);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
                                grads->hidden_w[l - 1], grads->hidden_b[l - 1], g.H, g.Hp, pl.wg_S);
         }
@@ -361,6 +446,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
 
     // coordinate layer
     const float* dh0 = pl.dh[cur];
+    Scope prof_l0(K_LAYER0_BWD, st);
     hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0, st,
                        pa, pl.posebuf, dh0, pl.sgpart, row_geo(g), pl.l0_oct_per_chunk, pl.l0_chunks_per_image);
     hipLaunchKernelGGL(sg_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp * kSlots)), dim3(256), 0, st, pl.sgpart, pl.sgimg,
@@ -391,6 +477,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
 int svae_bce_loglik(int32_t B, int32_t n, const float* y_hat, const float* target, float* loglik, float* dll_dy,
                     svae_stream_t stream) {
     if (B < 1 || n < 1 || !y_hat || !target || !loglik) return fail(SVAE_E_INVALID, "svae_bce_loglik: bad arguments");
+    Scope prof(K_BCE, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(bce_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), y_hat, target, loglik, dll_dy, n);
     return launch_status("svae_bce_loglik");
 }
@@ -418,9 +505,37 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
         filt = static_cast<float*>(ws);
         dflt = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
     }
+    Scope prof(K_GAUSSIAN, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(gaussian_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), y_params, target, mask, ctf,
                        k, loglik, dll_dy, filt, dflt, N, C);
     return launch_status("svae_gaussian_loglik");
 }
+
+int svae_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return SVAE_OK;
+}
+
+int svae_profile_read(double* ms_total, int64_t* launches) {
+    if (!ms_total || !launches) return fail(SVAE_E_INVALID, "svae_profile_read: null output");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int k = 0; k < SVAE_PROF_KINDS; ++k) {
+        ms_total[k] = 0.0;
+        launches[k] = 0;
+    }
+    for (const ProfRec& r : g_prof_used) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+            return fail(SVAE_E_LAUNCH, "svae_profile_read: event query failed");
+        ms_total[r.kind] += ms;
+        launches[r.kind] += 1;
+        g_prof_free.push_back(r);
+    }
+    g_prof_used.clear();
+    return SVAE_OK;
+}
+
+const char* svae_profile_kind_name(int kind) { return (kind >= 0 && kind < SVAE_PROF_KINDS) ? kKindNames[kind] : ""; }
 
 }  // extern "C"

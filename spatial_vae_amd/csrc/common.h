@@ -27,6 +27,7 @@
 namespace svae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int kSlots = 8;     // floats per (image, feature) entry of the first-layer table
 constexpr int kBiasSlot = 5;  // slot holding b_c[k] + (W_z z_b)[k]; slots 0..4 = effective coord weights

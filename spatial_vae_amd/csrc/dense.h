@@ -19,9 +19,9 @@ namespace svae {
 // MFMA roles (32x32x2: A lane l -> A[i=l&31][k=l>>5], B lane l -> B[k=l>>5][j=l&31]):
 //   A = row operand: lane (m = l&31, h = l>>5) supplies IN[m][8g + 4h + e] at step (g, e);
 //       one global dword per step, prefetched one octet (4 steps) ahead.
-//   B = packed weights from LDS: lane (n = l&31, h) reads the 16 bytes
-//       Wp[g][n][4h .. 4h+3] with one ds_read_b128 per 4 steps and column tile: the wave's 64
-//       lanes read 1 KiB contiguous, conflict-free.
+//   B = packed weights from LDS: lane (n = l&31, h) reads the 16 bytes W[n][8g + 4h .. +3] with
+//       one ds_read_b128 per 4 steps and column tile; slabs are stored [h][n][4] so that lane l
+//       reads bytes 16*l .. 16*l+15 of a 1 KiB slab: lane-linear, bank-conflict-free.
 //   D: lane (n, h) holds rows m = 8q + 4h + r (q = reg>>2, r = reg&3) of column n, i.e. four
 //       consecutive rows per register quad = one 16-byte octet-major store.
 // A workgroup is 4 waves = 4 consecutive row tiles sharing the weight chunks, which stream
@@ -31,7 +31,7 @@ namespace svae {
 // ------------------------------------------------------------------------------------------
 struct DenseArgs {
     const float* in;    // row operand, octet-major (Mp x Hp)
-    const float* wp;    // packed weights [Hp/8][Hp][8] (contraction index in the octet)
+    const float* wp;    // packed weights, 1 KiB slabs [Hp/8][Hp/32] of [k-quad 2][column 32][k 4] (pack_weights_kernel)
     float* out;         // octet-major (Mp x Hp)
     const float* bias;  // forward: (H) bias; data gradient: unused
     const float* aux;   // data gradient: a_{l-1} octet-major (its act' multiplies the result)
@@ -43,15 +43,10 @@ struct DenseArgs {
 };
 
 template <int ACT, bool DGRAD>
-__device__ __forceinline__ float4 dense_epilogue(float4 v, float bias, const float* resid_ptr, const float* aux_ptr) {
-    if (resid_ptr) {
-        const float4 r = *reinterpret_cast<const float4*>(resid_ptr);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
+__device__ __forceinline__ float4 dense_epilogue(float4 v, float bias, float4 aux) {
     if (DGRAD) {
-        const float4 a = *reinterpret_cast<const float4*>(aux_ptr);
-        v.x *= act_grad<ACT>(a.x); v.y *= act_grad<ACT>(a.y);
-        v.z *= act_grad<ACT>(a.z); v.w *= act_grad<ACT>(a.w);
+        v.x *= act_grad<ACT>(aux.x); v.y *= act_grad<ACT>(aux.y);
+        v.z *= act_grad<ACT>(aux.z); v.w *= act_grad<ACT>(aux.w);
     } else {
         v.x = act_fwd<ACT>(v.x + bias); v.y = act_fwd<ACT>(v.y + bias);
         v.z = act_fwd<ACT>(v.z + bias); v.w = act_fwd<ACT>(v.w + bias);
@@ -59,13 +54,80 @@ __device__ __forceinline__ float4 dense_epilogue(float4 v, float bias, const flo
     return v;
 }
 
-template <int NT, bool DGRAD>
+// One 1 KiB LDS-DMA piece: 64 lanes x 16 bytes, global (per-lane address) -> LDS (wave-uniform base in
+// M0 + 16*lane).  Issued through inline asm on purpose: for the builtin, hipcc assumes the DMA may alias
+// any later ds_read and puts s_waitcnt vmcnt(0) in front of it, which serialises the whole L2->LDS
+// latency into every chunk.  Hidden from the compiler, the pieces only ever make its own vmcnt waits
+// conservative; their completion is awaited by dma_wait_all() before the barrier that publishes them.
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_byte_addr)
+        : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Row operand of one 4-octet chunk: 16 dwords per lane at byte offsets 256*octet + 32*kstep from p.
+// Also asm, so that EVERY vector-memory operation of the main loop is invisible to hipcc's waitcnt
+// pass and the loop's two hand-counted s_waitcnt are the only ones (see the queue proof at the loop).
+// hipcc regards the destinations as written the moment the statement ends: it must never get a reason
+// to copy, spill or re-home them before wait_vm_chunk (a loop-carried phi copy of in-flight registers
+// once sent the late data into the DMA address register: memory fault).  Hence (1) the operands are
+// "+v" -- the load lands in the registers the variable already lives in -- and (2) load and wait sit in
+// the SAME loop iteration, so no in-flight value crosses a back-edge.  tools/check_asm_loads.py
+// verifies on the ISA that nothing touches a destination between its load and its wait.
+__device__ __forceinline__ void load_a_chunk(const float* p, float (&v)[4][4]) {
+    asm volatile(
+        "global_load_dword %0, %16, off\n\t"
+        "global_load_dword %1, %16, off offset:32\n\t"
+        "global_load_dword %2, %16, off offset:64\n\t"
+        "global_load_dword %3, %16, off offset:96\n\t"
+        "global_load_dword %4, %16, off offset:256\n\t"
+        "global_load_dword %5, %16, off offset:288\n\t"
+        "global_load_dword %6, %16, off offset:320\n\t"
+        "global_load_dword %7, %16, off offset:352\n\t"
+        "global_load_dword %8, %16, off offset:512\n\t"
+        "global_load_dword %9, %16, off offset:544\n\t"
+        "global_load_dword %10, %16, off offset:576\n\t"
+        "global_load_dword %11, %16, off offset:608\n\t"
+        "global_load_dword %12, %16, off offset:768\n\t"
+        "global_load_dword %13, %16, off offset:800\n\t"
+        "global_load_dword %14, %16, off offset:832\n\t"
+        "global_load_dword %15, %16, off offset:864"
+        : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[1][0]), "+v"(v[1][1]),
+          "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]),
+          "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3])
+        : "v"(p)
+        : "memory");
+}
+// wait until at most N vector-memory operations of this wave are outstanding; the chunk registers are
+// passed through so that no use of them can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void wait_vm_chunk(float (&v)[4][4]) {
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[1][0]), "+v"(v[1][1]),
+                   "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]),
+                   "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3])
+                 : "i"(N)
+                 : "memory");
+}
+
+template <int NT>
+struct DenseCfg {
+    static constexpr int NB = NT * 32;                 // columns per accumulation block
+    static constexpr int G = 4;                        // contraction octets per LDS chunk
+    static constexpr int CHUNK = G * NB * 8;           // floats per LDS buffer
+    static constexpr int LDS_BYTES = 2 * CHUNK * 4;    // two buffers
+    static constexpr int NINSTR = G * NT;              // 1 KiB global_load_lds wave-instructions per chunk
+};
+
+template <int NT, bool DGRAD, bool RESID>
 __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NB = NT * 32;            // columns per accumulation block
-    constexpr int G = (NT == 16) ? 2 : 4;  // contraction octets per LDS chunk
-    constexpr int CHUNK = G * NB * 8;      // floats per LDS buffer
-    constexpr int NINSTR = G * NT;         // 1 KiB global_load_lds wave-instructions per chunk
+    using Cfg = DenseCfg<NT>;
+    constexpr int NB = Cfg::NB, G = Cfg::G, CHUNK = Cfg::CHUNK, NINSTR = Cfg::NINSTR;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -74,11 +136,14 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
     const bool live = tile < a.tiles;
     const long tl = live ? tile : a.tiles - 1;  // dead waves recompute the last tile and store nothing
     const int Hp = a.Hp;
-    const int noct = Hp / 8;
+    const int noct = Hp / 8;       // multiple of 4
     const int nchunk = noct / G;
 
     // this lane's row (m = nl) of the row operand: element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)
     const float* arow = a.in + ((tl * 4 + (nl >> 3)) * (long)Hp + 4 * h) * 8 + (nl & 7);
+    const float* bfrag = smem + lane * 4;  // this lane's 16 bytes of a 1 KiB (32-column x 8-k) slab
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const int ntile = Hp / 32;
 
     for (int nb = 0; nb < Hp / NB; ++nb) {
         f32x16 acc[NT];
@@ -87,72 +152,138 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+        // weight chunk c (G contraction octets x NT column tiles, 1 KiB slabs) -> LDS buffer buf
         auto stage = [&](int c, int buf) {
 #pragma unroll
-            for (int j = 0; j < (NINSTR + 3) / 4; ++j) {
+            for (int j = 0; j < NINSTR / 4; ++j) {
                 const int idx = wave + 4 * j;
-                if (idx < NINSTR) {
-                    const int gl = idx / NT, tt = idx % NT;
-                    const float* src = a.wp + (((long)(c * G + gl) * Hp + nb * NB + tt * 32) * 8) + lane * 4;
-                    float* dst = smem + buf * CHUNK + (gl * NB + tt * 32) * 8;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                }
+                const int gl = idx / NT, tt = idx % NT;
+                const float* src = a.wp + ((long)(c * G + gl) * ntile + nb * NT + tt) * 256 + lane * 4;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK + idx * 256) * 4u));
             }
         };
-
-        stage(0, 0);
-        float av[4];
+        // B fragments of contraction octet o: NT x 16 bytes per lane (4 k-steps each), conflict-free
+        auto read_b = [&](int o, float4 (&b)[NT]) {
+            const float* base = bfrag + ((o / G) & 1) * CHUNK + (o % G) * NT * 256;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[e] = arow[e * 8];
+            for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(base + t * 256);
+        };
+        auto mfma_octet = [&](const float (&av)[4], const float4 (&bc)[NT]) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bc[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bc[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bc[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bc[t].w, acc[t], 0, 0, 0);
+        };
 
+        // Main loop.  No branches (indices past the end are clamped: a harmless re-read / re-stage of
+        // valid data) and no compiler-visible vector-memory operation, so the only vmcnt waits are the
+        // two below.  Per wave the VMEM queue, oldest first, cycles through
+        //     ... DMA(c+1)[P] |top of chunk c| A(c+1)[16] |barrier of chunk c| DMA(c+2)[P] |end of chunk c| ...
+        // (P = NINSTR/4 DMA pieces per wave), hence
+        //     before the barrier of chunk c : vmcnt(16) -> DMA(c+1) has landed, A(c+1) may be in flight
+        //     at the end of chunk c         : vmcnt(P)  -> A(c+1) has landed, DMA(c+2) may be in flight
+        constexpr int P = NINSTR / 4;
+        static_assert(G == 4, "load_a_chunk moves 4 octets");
+        stage(0, 0);
+        stage(nchunk > 1 ? 1 : 0, 1);
+        float ac[G][4], an[G][4];
+        float4 b0[NT], b1[NT];
+#pragma unroll
+        for (int gl = 0; gl < G; ++gl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) an[gl][e] = 0.0f;
+        load_a_chunk(arow, an);
+        wait_vm_chunk<0>(an);
+        __syncthreads();  // chunks 0 and 1 have landed in LDS
+#pragma unroll
+        for (int gl = 0; gl < G; ++gl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ac[gl][e] = an[gl][e];
+        read_b(0, b0);
+        const int spare = nchunk & 1;  // buffer that held chunk nchunk-2: the sink of redundant re-stages
         for (int c = 0; c < nchunk; ++c) {
-            __syncthreads();  // chunk c has landed (vmcnt drained) and buffer (c+1)&1 is free again
-            if (c + 1 < nchunk) stage(c + 1, (c + 1) & 1);
-            const float* bbuf = smem + (c & 1) * CHUNK + nl * 8 + 4 * h;
+            // A(c+1): issued here, awaited at the bottom of this same iteration (a whole chunk later)
+            load_a_chunk(arow + (long)(c + 1 < nchunk ? c + 1 : nchunk - 1) * (G * 64), an);
 #pragma unroll
             for (int gl = 0; gl < G; ++gl) {
-                const int gnext = c * G + gl + 1;
-                float an[4];
+                const int o = c * G + gl;
+                if (gl == G - 1) {
+                    // the next octet opens chunk c+1: its DMA must have landed in every wave's view, and
+                    // every wave must hold its last fragments of chunk c before that buffer is reused
+                    wait_vm_chunk<16>(ac);
+                    __syncthreads();
+                    const bool more = c + 2 < nchunk;
+                    stage(more ? c + 2 : nchunk - 1, more ? (c & 1) : spare);
+                }
+                const int onext = (o + 1 < noct) ? o + 1 : noct - 1;
+                if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gl & 1) mfma_octet(ac[gl], b1); else mfma_octet(ac[gl], b0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_vm_chunk<P>(an);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) an[e] = (gnext < noct) ? arow[(long)gnext * 64 + e * 8] : 0.0f;
+            for (int gl = 0; gl < G; ++gl)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ac[gl][e] = an[gl][e];
+        }
+        dma_wait_all();  // the last (redundant) DMA pieces, before compiler-visible memory traffic
+
+        // ---- epilogue: bias/activation (forward) or act' of the previous layer (data gradient).
+        // vmcnt counts stores as well as loads, in issue order: a load issued after a store cannot be
+        // waited for without also waiting for that store.  So all loads of column tile t+1 (bias is
+        // batched up front) are issued BEFORE the stores of tile t, and nothing in here branches.
+        if (live) {
+            auto epi = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+                float bias[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float4 b = *reinterpret_cast<const float4*>(bbuf + (gl * NB + t * 32) * 8);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], b.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], b.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], b.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], b.w, acc[t], 0, 0, 0);
+                    const int n = nb * NB + t * 32 + nl;
+                    const float bv = DGRAD ? 0.0f : a.bias[n < a.H ? n : a.H - 1];
+                    bias[t] = (n < a.H) ? bv : 0.0f;
                 }
+                const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;  // (q = 0, t = 0)
+                const long qstride = (long)Hp * 8;                                  // next row octet
+                float4 xa[2][4], xr[2][4];  // aux (data gradient) and residual operands of tile t / t+1
+                auto fetch = [&](int t, float4 (&fa)[4], float4 (&fr)[4]) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) av[e] = an[e];
+                    for (int q = 0; q < 4; ++q) {
+                        const long off = off0 + q * qstride + (long)t * 32 * 8;
+                        if (DGRAD) fa[q] = *reinterpret_cast<const float4*>(a.aux + off);
+                        if (RESID) fr[q] = *reinterpret_cast<const float4*>(a.in + off);
+                    }
+                };
+                auto finish = [&](int t, const float4 (&fa)[4], const float4 (&fr)[4]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                        if (RESID) {
+                            v.x += fr[q].x; v.y += fr[q].y; v.z += fr[q].z; v.w += fr[q].w;
+                        }
+                        v = dense_epilogue<ACT, DGRAD>(v, bias[t], fa[q]);
+                        *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = v;
+                    }
+                };
+                if (DGRAD || RESID) fetch(0, xa[0], xr[0]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if ((DGRAD || RESID) && t + 1 < NT) fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
+                    finish(t, xa[t & 1], xr[t & 1]);
+                }
+            };
+            switch (a.act) {
+                case SVAE_ACT_TANH: epi(std::integral_constant<int, SVAE_ACT_TANH>()); break;
+                case SVAE_ACT_LEAKYRELU: epi(std::integral_constant<int, SVAE_ACT_LEAKYRELU>()); break;
+                case SVAE_ACT_RELU: epi(std::integral_constant<int, SVAE_ACT_RELU>()); break;
+                default: epi(std::integral_constant<int, SVAE_ACT_SIGMOID>()); break;
             }
         }
-
-        // ---- epilogue: bias/activation (forward) or act' of the previous layer (data gradient)
-        auto epi = [&](auto act_tag) {
-            constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = nb * NB + t * 32 + nl;
-                float bias = 0.0f;
-                if (!DGRAD) bias = (n < a.H) ? a.bias[n] : 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const long off = ((tl * 4 + q) * (long)Hp + n) * 8 + 4 * h;
-                    float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
-                    v = dense_epilogue<ACT, DGRAD>(v, bias, a.resid ? a.in + off : nullptr, DGRAD ? a.aux + off : nullptr);
-                    if (live) *reinterpret_cast<float4*>(a.out + off) = v;
-                }
-            }
-        };
-        switch (a.act) {
-            case SVAE_ACT_TANH: epi(std::integral_constant<int, SVAE_ACT_TANH>()); break;
-            case SVAE_ACT_LEAKYRELU: epi(std::integral_constant<int, SVAE_ACT_LEAKYRELU>()); break;
-            case SVAE_ACT_RELU: epi(std::integral_constant<int, SVAE_ACT_RELU>()); break;
-            default: epi(std::integral_constant<int, SVAE_ACT_SIGMOID>()); break;
-        }
-        __syncthreads();  // every wave is done with the LDS buffers before the next block restages buffer 0
+        __syncthreads();  // every wave is done with the LDS buffers before the next block restages them
     }
 }
 
@@ -174,6 +305,8 @@ struct WgradArgs {
     int Hp;
     int nblk1;           // blocks per side = ceil(ntile / 8)
 };
+
+constexpr int kWgradLdsBytes = 4 * 4 * 8 * 1024;  // 4 waves x 4 ring slots x 8 KiB
 
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
@@ -205,45 +338,80 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    float4 ac[4], bc[4];
+    // Operands stream HBM/L2 -> LDS by LDS-DMA into a PRIVATE ring of this wave (4 slots x 8 pieces of
+    // 1 KiB: dh tiles 0-3, a_prev tiles 0-3; lane l's 16 bytes at 16*l of a piece = conflict-free
+    // ds_read_b128), three octets ahead of the MFMAs; fragments move LDS -> registers one octet ahead
+    // with ordinary (compiler-visible) ds_reads.  An octet is 64 MFMAs = 4096 cycles, a loaded-chip HBM
+    // round trip is about as long, hence the depth.  No asm load has a register destination here: hipcc
+    // re-homes in-flight registers of such loads across the loop back-edge (see load_a_chunk), and a ring
+    // cannot avoid having loads in flight there.  No barrier either: the ring belongs to one wave.
+    // Queue per wave, oldest first, when the fragments of octet o+1 are about to be read:
+    //     DMA(o+1)[8] DMA(o+2)[8] DMA(o+3)[8]   ->  s_waitcnt vmcnt(16).
+    // The loop is branch-free: DMA and fragment reads past the end are clamped re-loads that are never
+    // multiplied.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int kSlotFloats = 8 * 256;  // 8 KiB
+    float* ring = smem + wave * (4 * kSlotFloats);
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
     const long ostride = (long)Hp * 8;
+    auto dma = [&](long o) {
+        const long oc = (o < o1) ? o : o1 - 1;
+        const long off = oc * ostride;
+        const unsigned slot = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((o - o0) & 3) * (kSlotFloats * 4u));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(pa[t] + off, slot + t * 1024u);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(pb[t] + off, slot + (4 + t) * 1024u);
+    };
+    auto frag = [&](long o, float4 (&xa)[4], float4 (&xb)[4]) {
+        const float* sl = ring + ((o - o0) & 3) * kSlotFloats + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xa[t] = *reinterpret_cast<const float4*>(sl + t * 256);
+            xb[t] = *reinterpret_cast<const float4*>(sl + (4 + t) * 256);
+        }
+    };
+    auto mul = [&](const float4 (&xa)[4], const float4 (&xb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].x, xb[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].y, xb[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].z, xb[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, xb[j].w, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bs[t] += (xa[t].x + xa[t].y) + (xa[t].z + xa[t].w);
+    };
     if (o0 < o1) {
+        float4 ca[4], cb[4], na[4], nb[4];
+        dma(o0);
+        dma(o0 + 1);
+        dma(o0 + 2);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        frag(o0, ca, cb);
+        for (long o = o0; o < o1; ++o) {
+            dma(o + 3);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // DMA(o+1) has landed
+            frag(o + 1, na, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            ac[t] = *reinterpret_cast<const float4*>(pa[t] + o0 * ostride);
-            bc[t] = *reinterpret_cast<const float4*>(pb[t] + o0 * ostride);
+            for (int t = 0; t < 4; ++t) {
+                ca[t] = na[t];
+                cb[t] = nb[t];
+            }
         }
-    }
-    for (long o = o0; o < o1; ++o) {
-        float4 an[4], bn[4];
-        const long on = (o + 1 < o1) ? o + 1 : o;  // last iteration reloads the same octet (harmless)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            an[t] = *reinterpret_cast<const float4*>(pa[t] + on * ostride);
-            bn[t] = *reinterpret_cast<const float4*>(pb[t] + on * ostride);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i].x, bc[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i].y, bc[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i].z, bc[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i].w, bc[j].w, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            bs[t] += (ac[t].x + ac[t].y) + (ac[t].z + ac[t].w);
-            ac[t] = an[t];
-            bc[t] = bn[t];
-        }
+        dma_wait_all();  // the clamped pieces still in flight (they only ever target this wave's ring)
     }
 
     float* slab = a.slab + (long)blockIdx.y * Hp * Hp;

@@ -8,17 +8,22 @@
 namespace svae {
 
 // ---------------------------------------------------------------- weight packing
-// W (H x H, row-major [n][k]) -> both contraction-octet-major images, zero-padded to Hp:
-//   wf[(k>>3)*Hp + n][k&7] : forward (contract over k, lane = n)
-//   wb[(n>>3)*Hp + k][n&7] : data gradient (contract over n, lane = k)
+// W (H x H, row-major [n][k]) -> the two LDS images of dense_kernel, zero-padded to Hp.  An image is
+// an array of 1 KiB slabs [contraction octet g][output tile t]; inside a slab [quad hh][lane 32][4]:
+//   wf (forward, contract over k, lane = n):        k = 8g + 4hh + e, n = 32t + lane
+//   wb (data gradient, contract over n, lane = k):  n = 8g + 4hh + e, k = 32t + lane
+// so that MFMA lane l = lane + 32*hh finds its four k-steps at bytes 16*l of the slab.
+__device__ __forceinline__ long slab_index(int contr, int out, int ntile) {
+    return (((long)(contr >> 3) * ntile + (out >> 5)) * 2 + ((contr >> 2) & 1)) * 128 + (out & 31) * 4 + (contr & 3);
+}
 __global__ void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ wf, float* __restrict__ wb, int H,
                                     int Hp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Hp * Hp) return;
     const int n = idx / Hp, k = idx % Hp;
     const float v = (n < H && k < H) ? W[(long)n * H + k] : 0.0f;
-    wf[((long)(k >> 3) * Hp + n) * 8 + (k & 7)] = v;
-    wb[((long)(n >> 3) * Hp + k) * 8 + (n & 7)] = v;
+    wf[slab_index(k, n, Hp / 32)] = v;
+    wb[slab_index(n, k, Hp / 32)] = v;
 }
 
 // ---------------------------------------------------------------- per-image tables

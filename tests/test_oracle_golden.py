@@ -53,3 +53,24 @@ def test_saturated_case_hits_the_bce_clamp():
     gold = load_golden("mnist_saturated")
     assert (gold["y_hat"] == 1.0).any() or (gold["y_hat"] == 0.0).any()
     assert float(gold["log_p"]) < -1000
+
+
+@pytest.mark.parametrize("name", ["mnist_rt", "mnist_r", "mnist_t", "mnist_none", "mnist_leaky", "mnist_dxscale"])
+def test_torch_cpu_step_matches_reference(name):
+    """The torch-CPU restatement timed as cpu_baseline computes the reference's numbers."""
+    import torch
+    from oracle import torch_cpu_step as T
+    case = C.CASES_BY_NAME[name]
+    inp = C.build_inputs(case)
+    gold = load_golden(name)
+    pp = {k: torch.tensor(v).requires_grad_(True) for k, v in inp["p_state"].items()}
+    qp = {k: torch.tensor(v).requires_grad_(True) for k, v in inp["q_state"].items()}
+    elbo, log_p, kl, y_hat = T.elbo_mnist(pp, qp, torch.from_numpy(inp["x_coord"]), torch.from_numpy(inp["y"]),
+                                          torch.from_numpy(inp["r"]), act=case["act"], rotate=case["rotate"],
+                                          translate=case["translate"], dx_scale=case["dx_scale"],
+                                          theta_prior=case["theta_prior"])
+    (-elbo).backward()
+    assert abs(elbo.item() - float(gold["elbo"])) <= TOL * abs(float(gold["elbo"]))
+    assert rel_err(y_hat.detach().numpy(), gold["y_hat"]) < TOL
+    check_grads("gp.", {k: v.grad.numpy() for k, v in pp.items()}, gold, case, 5 * TOL)
+    check_grads("gq.", {k: v.grad.numpy() for k, v in qp.items()}, gold, case, 5 * TOL)
