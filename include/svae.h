@@ -170,8 +170,9 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
                          void* ws, size_t ws_bytes, svae_stream_t stream);
 
 /*
- * Optional per-kernel timing (bench.py's roofline figure).  While enabled, every kernel launch of
- * this library is bracketed by two HIP events recorded on the launch stream; svae_profile_read
+ * Optional per-kernel timing (bench.py's roofline figure).  While enabled (on = 1: only the three MFMA
+ * GEMM kernels, on = 2: every kernel, 0 = off), kernel launches of
+ * this library are bracketed by two HIP events recorded on the launch stream; svae_profile_read
  * synchronises those events and returns, per kernel kind, the summed device time in ms and the
  * number of launches, then clears the records.  Not for use under stream capture.  The reference
  * has no counterpart (it has no profiling at all: SURVEY.md section 5).

@@ -89,8 +89,9 @@ def check(rc):
         raise RuntimeError("svae: %s (code %d)" % (lib().svae_last_error().decode(), rc))
 
 
-def profile_enable(on):
-    check(lib().svae_profile_enable(1 if on else 0))
+def profile_enable(level):
+    """0 = off, 1 = the three MFMA GEMM kernels only (cheap enough for a timed region), 2 = every kernel."""
+    check(lib().svae_profile_enable(int(level)))
 
 
 def profile_read():

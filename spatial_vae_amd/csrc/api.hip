@@ -51,6 +51,7 @@ struct Plan {
     float* slab;
     float* bslab;
     float* wpart;
+    float* bpart;
     float* sgpart;
     float* sgimg;
     float* dcoords;
@@ -82,7 +83,7 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     {
         long rc = g.noct / 32;
         if (rc < 1) rc = 1;
-        if (rc > 512) rc = 512;
+        if (rc > 256) rc = 256;
         p.ob_oct_per_chunk = (g.noct + rc - 1) / rc;
         p.ob_chunks = (int)((g.noct + p.ob_oct_per_chunk - 1) / p.ob_oct_per_chunk);
     }
@@ -111,6 +112,7 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.slab = cw.take<float>((size_t)p.wg_S * g.Hp * g.Hp);
     p.bslab = cw.take<float>((size_t)p.wg_S * 2 * g.Hp);
     p.wpart = cw.take<float>((size_t)p.ob_chunks * 2 * g.C * g.Hp);
+    p.bpart = cw.take<float>((size_t)p.ob_chunks * 2 * g.C);
     p.sgpart = cw.take<float>((size_t)g.B * p.l0_chunks_per_image * g.Hp * 2 * kSlots);
     p.sgimg = cw.take<float>((size_t)g.B * g.Hp * kSlots);
     p.dcoords = cw.take<float>((size_t)g.B * g.N * 2);
@@ -161,7 +163,7 @@ const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense
                                                  "gaussian", "", "", ""};
 struct ProfRec { hipEvent_t a, b; int kind; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+int g_prof_level = 0;  // 0 off, 1 = the three MFMA GEMM kernels only, 2 = every kernel
 std::vector<ProfRec> g_prof_used, g_prof_free;
 
 struct Scope {  // brackets the launches issued during its lifetime
@@ -170,7 +172,8 @@ struct Scope {  // brackets the launches issued during its lifetime
     bool on;
     Scope(int kind, hipStream_t s) : st(s), on(false) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (!g_prof_on) return;
+        if (g_prof_level == 0) return;
+        if (g_prof_level == 1 && kind != K_DENSE_FWD && kind != K_DENSE_DGRAD && kind != K_WGRAD) return;
         if (!g_prof_free.empty()) {
             rec = g_prof_free.back();
             g_prof_free.pop_back();
@@ -256,8 +259,9 @@ int dense_nt_for(int ntile) {
 template <bool DGRAD>
 void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
-    const dim3 grid((unsigned)((g.tiles + 3) / 4));
-    switch (dense_nt_for(g.ntile)) {
+    const int nt = dense_nt_for(g.ntile);
+    const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
+    switch (nt) {
         case 16: launch_dense_nt<16, DGRAD>(a, grid, st); break;
         case 8: launch_dense_nt<8, DGRAD>(a, grid, st); break;
         case 4: launch_dense_nt<4, DGRAD>(a, grid, st); break;
@@ -287,7 +291,7 @@ template <int ACT, int C>
 void launch_out_bwd_ac(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh, hipStream_t st) {
     Scope prof(K_OUT_BWD, st);
     hipLaunchKernelGGL((out_bwd_kernel<ACT, C>), dim3(blocks_for(g.Hp * 2), pl.ob_chunks), dim3(256), 0, st, a, pl.do_p,
-                       p->out_w, dh, pl.wpart, g.H, g.Hp, (long)g.Mp, g.noct, pl.ob_oct_per_chunk);
+                       p->out_w, dh, pl.wpart, pl.bpart, g.H, g.Hp, (long)g.Mp, g.noct, pl.ob_oct_per_chunk);
 }
 template <int ACT>
 void launch_out_bwd_a(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh, hipStream_t st) {
@@ -400,8 +404,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     }
     {
         Scope prof(K_SMALL_BWD, st);
-        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C + blocks_for((long)g.C * g.H)), dim3(256), 0, st, pl.wpart,
-                           pl.do_p, grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2, (long)g.Mp);
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
+                           grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2);
     }
 
     // hidden layers, last to first
@@ -452,7 +456,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     hipLaunchKernelGGL(sg_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp * kSlots)), dim3(256), 0, st, pl.sgpart, pl.sgimg,
                        g.B, g.Hp, pl.l0_chunks_per_image);
     const bool bil = (g.flags & SVAE_FLAG_BILINEAR) != 0;
-    hipLaunchKernelGGL(layer0_param_grads_kernel, dim3(blocks_for(g.H)), dim3(256), 0, st, pl.sgimg, z, grads->coord_w,
+    hipLaunchKernelGGL(layer0_param_grads_kernel, dim3(blocks_for((long)g.H * kSlots)), dim3(256), 0, st, pl.sgimg, z, grads->coord_w,
                        grads->coord_b, g.Zd > 0 ? grads->latent_w : nullptr, bil ? grads->bilinear_w : nullptr, g.B, g.H,
                        g.Hp, g.Zd, g.in_dim);
     if (dz && g.Zd > 0)
@@ -513,7 +517,7 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
 
 int svae_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+    g_prof_level = on < 0 ? 0 : (on > 2 ? 2 : on);
     return SVAE_OK;
 }
 

@@ -114,6 +114,14 @@ __device__ __forceinline__ void wait_vm_chunk(float (&v)[4][4]) {
                  : "memory");
 }
 
+// Timing-only ablation switches for tools/dense_ablate.hip (never defined in the product build):
+//   1 = no epilogue   2 = no barrier / LDS-DMA in the loop   4 = no B-fragment reads in the loop
+//   8 = no A-operand loads in the loop   16 = half of the MFMAs   32 = every tile reads the rows of tile 0
+//   64 = LDS-DMA issued but never awaited and no barrier
+#ifndef SVAE_ABLATE
+#define SVAE_ABLATE 0
+#endif
+
 template <int NT>
 struct DenseCfg {
     static constexpr int NB = NT * 32;                 // columns per accumulation block
@@ -140,12 +148,16 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
     const int nchunk = noct / G;
 
     // this lane's row (m = nl) of the row operand: element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)
-    const float* arow = a.in + ((tl * 4 + (nl >> 3)) * (long)Hp + 4 * h) * 8 + (nl & 7);
+    const float* arow = a.in + ((((SVAE_ABLATE & 32) ? 0 : tl) * 4 + (nl >> 3)) * (long)Hp + 4 * h) * 8 + (nl & 7);
     const float* bfrag = smem + lane * 4;  // this lane's 16 bytes of a 1 KiB (32-column x 8-k) slab
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     const int ntile = Hp / 32;
 
-    for (int nb = 0; nb < Hp / NB; ++nb) {
+    // one column block (NB columns) per workgroup: blockIdx.y.  Keeping the work quantum at
+    // 32 rows x NB columns (not x Hp) gives the dispatcher twice as many, half as long workgroups to
+    // balance over the 256 CUs x 2 resident workgroups (6.25 rounds instead of 3.1 at BASELINE cfg 2).
+    {
+        const int nb = blockIdx.y;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -207,22 +219,28 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
         const int spare = nchunk & 1;  // buffer that held chunk nchunk-2: the sink of redundant re-stages
         for (int c = 0; c < nchunk; ++c) {
             // A(c+1): issued here, awaited at the bottom of this same iteration (a whole chunk later)
-            load_a_chunk(arow + (long)(c + 1 < nchunk ? c + 1 : nchunk - 1) * (G * 64), an);
+            if (!(SVAE_ABLATE & 8)) load_a_chunk(arow + (long)(c + 1 < nchunk ? c + 1 : nchunk - 1) * (G * 64), an);
 #pragma unroll
             for (int gl = 0; gl < G; ++gl) {
                 const int o = c * G + gl;
-                if (gl == G - 1) {
+                if (gl == G - 1 && !(SVAE_ABLATE & 2)) {
                     // the next octet opens chunk c+1: its DMA must have landed in every wave's view, and
                     // every wave must hold its last fragments of chunk c before that buffer is reused
-                    wait_vm_chunk<16>(ac);
-                    __syncthreads();
+                    if (!(SVAE_ABLATE & 64)) {
+                        wait_vm_chunk<16>(ac);
+                        __syncthreads();
+                    }
                     const bool more = c + 2 < nchunk;
                     stage(more ? c + 2 : nchunk - 1, more ? (c & 1) : spare);
                 }
                 const int onext = (o + 1 < noct) ? o + 1 : noct - 1;
-                if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
+                if (!(SVAE_ABLATE & 4)) {
+                    if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (gl & 1) mfma_octet(ac[gl], b1); else mfma_octet(ac[gl], b0);
+                if (!(SVAE_ABLATE & 16) || (gl & 1)) {
+                    if (gl & 1) mfma_octet(ac[gl], b1); else mfma_octet(ac[gl], b0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             wait_vm_chunk<P>(an);
@@ -237,7 +255,14 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
         // vmcnt counts stores as well as loads, in issue order: a load issued after a store cannot be
         // waited for without also waiting for that store.  So all loads of column tile t+1 (bias is
         // batched up front) are issued BEFORE the stores of tile t, and nothing in here branches.
-        if (live) {
+        if (SVAE_ABLATE & 1) {
+            if (a.tiles < 0) {  // never true: keeps the accumulators alive without an epilogue
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a.out[t * 16 + r] = acc[t][r];
+            }
+        } else if (live) {
             auto epi = [&](auto act_tag) {
                 constexpr int ACT = decltype(act_tag)::value;
                 float bias[NT];
@@ -283,7 +308,6 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
                 default: epi(std::integral_constant<int, SVAE_ACT_SIGMOID>()); break;
             }
         }
-        __syncthreads();  // every wave is done with the LDS buffers before the next block restages them
     }
 }
 

@@ -174,15 +174,16 @@ __global__ void dlogits_kernel(const float* __restrict__ logits, const float* __
 template <int ACT, int C>
 __global__ void out_bwd_kernel(const float* __restrict__ a, const float* __restrict__ do_p,
                                const float* __restrict__ out_w, float* __restrict__ dh, float* __restrict__ wpart,
-                               int H, int Hp, long Mp, long noct, long oct_per_chunk) {
+                               float* __restrict__ bpart, int H, int Hp, long Mp, long noct, long oct_per_chunk) {
     const int t = blockIdx.x * 256 + threadIdx.x;  // over Hp*2
     if (t >= Hp * 2) return;
     const int h = t & 1, n = t >> 1;
-    float w[C], pw[C];
+    float w[C], pw[C], pb[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         w[c] = (n < H) ? out_w[c * H + n] : 0.0f;
         pw[c] = 0.0f;
+        pb[c] = 0.0f;
     }
     const long o0 = blockIdx.y * oct_per_chunk;
     const long o1 = (o0 + oct_per_chunk < noct) ? o0 + oct_per_chunk : noct;
@@ -195,6 +196,7 @@ __global__ void out_bwd_kernel(const float* __restrict__ a, const float* __restr
             const float4 d = *reinterpret_cast<const float4*>(do_p + (long)c * Mp + 8 * o + 4 * h);
             da.x += d.x * w[c]; da.y += d.y * w[c]; da.z += d.z * w[c]; da.w += d.w * w[c];
             pw[c] += (d.x * av.x + d.y * av.y) + (d.z * av.z + d.w * av.w);
+            pb[c] += (d.x + d.y) + (d.z + d.w);
         }
         da.x *= act_grad<ACT>(av.x); da.y *= act_grad<ACT>(av.y);
         da.z *= act_grad<ACT>(av.z); da.w *= act_grad<ACT>(av.w);
@@ -202,27 +204,42 @@ __global__ void out_bwd_kernel(const float* __restrict__ a, const float* __restr
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) wpart[(((long)blockIdx.y * 2 + h) * C + c) * Hp + n] = pw[c];
+    if (n == 0) {  // the two half-wave threads of column 0 also carry this chunk's share of db_o
+#pragma unroll
+        for (int c = 0; c < C; ++c) bpart[((long)blockIdx.y * 2 + h) * C + c] = pb[c];
+    }
 }
 
-// dW_o[c][n] = sum over (chunk, half) of wpart; db_o[c] = sum_m do[m][c]
-__global__ void out_bwd_reduce_kernel(const float* __restrict__ wpart, const float* __restrict__ do_p,
+// dW_o[c][n] = sum over (chunk, half) of wpart; db_o[c] = sum over (chunk, half) of bpart.  The order is
+// fixed (8 interleaved partial sums per column, combined in LDS in a fixed order).  A block owns 32
+// consecutive columns of one channel: thread = (column, part lane), so every sweep over the partials is a
+// coalesced 128-byte read and 8 independent chains run per column.
+__global__ void out_bwd_reduce_kernel(const float* __restrict__ wpart, const float* __restrict__ bpart,
                                       float* __restrict__ dWo, float* __restrict__ dbo, int C, int H, int Hp,
-                                      int nparts, long Mp) {
-    __shared__ float red[4];
-    if (blockIdx.x < (unsigned)C) {  // one block per channel: bias gradient
-        const int c = blockIdx.x;
-        float s = 0.0f;
-        for (long m = threadIdx.x; m < Mp; m += 256) s += do_p[(long)c * Mp + m];
-        s = block_sum256(s, red);
-        if (threadIdx.x == 0 && dbo) dbo[c] = s;
+                                      int nparts) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int blocks_per_c = Hp / 32;
+    if (blockIdx.x == (unsigned)(C * blocks_per_c)) {  // last block: the C bias gradients
+        if (threadIdx.x < C && dbo) {
+            float s = 0.0f;
+            for (int i = 0; i < nparts; ++i) s += bpart[(long)i * C + threadIdx.x];
+            dbo[threadIdx.x] = s;
+        }
         return;
     }
-    const long idx = (long)(blockIdx.x - C) * 256 + threadIdx.x;
-    if (idx >= (long)C * H || !dWo) return;
-    const int c = idx / H, n = idx % H;
+    const int c = blockIdx.x / blocks_per_c, n = (blockIdx.x % blocks_per_c) * 32 + col;
     float s = 0.0f;
-    for (int i = 0; i < nparts; ++i) s += wpart[((long)i * C + c) * Hp + n];
-    dWo[idx] = s;
+#pragma unroll 4
+    for (int i = pl; i < nparts; i += 8) s += wpart[((long)i * C + c) * Hp + n];
+    red[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && n < H && dWo) {
+        float t = red[0][col];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += red[j][col];
+        dWo[(long)c * H + n] = t;
+    }
 }
 
 // ---------------------------------------------------------------- coordinate layer, backward
@@ -323,37 +340,44 @@ __global__ void layer0_bwd_coords_kernel(PoseArgs pose, const float4* __restrict
     }
 }
 
-// (c) first-layer parameter gradients from the per-image sums (one thread per feature k):
+// (c) first-layer parameter gradients from the per-image sums.  Thread = (k, slot): consecutive threads
+//     read consecutive floats of sgimg[b], so each of the B passes is one coalesced sweep.
 //     dW_c[k][p] = sum_b G_b[k][p];  db_c[k] = sum_b S_b[k];  dW_z[k][q] = sum_b S_b[k] z[b][q];
 //     dW_bi[k][p][q] = sum_b G_b[k][p] z[b][q]
+constexpr int kZChunk = 16;
 __global__ void layer0_param_grads_kernel(const float* __restrict__ sgimg, const float* __restrict__ z,
                                           float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWz,
                                           float* __restrict__ dWbi, int B, int H, int Hp, int Zd, int in_dim) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= H) return;
-    float G[5] = {0, 0, 0, 0, 0};
-    float S = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        const float* e = sgimg + ((long)b * Hp + k) * kSlots;
-        for (int p = 0; p < in_dim; ++p) G[p] += e[p];
-        S += e[kBiasSlot];
-    }
-    if (dWc)
-        for (int p = 0; p < in_dim; ++p) dWc[k * in_dim + p] = G[p];
-    if (dbc) dbc[k] = S;
-    if (dWz)
-        for (int q = 0; q < Zd; ++q) {
-            float s = 0.0f;
-            for (int b = 0; b < B; ++b) s += sgimg[((long)b * Hp + k) * kSlots + kBiasSlot] * z[(long)b * Zd + q];
-            dWz[(long)k * Zd + q] = s;
+    const int t = blockIdx.x * 256 + threadIdx.x;  // over H * kSlots
+    if (t >= H * kSlots) return;
+    const int k = t / kSlots, slot = t % kSlots;
+    const bool is_g = slot < in_dim, is_s = slot == kBiasSlot;
+    if (!is_g && !is_s) return;
+    const float* src = sgimg + (long)k * kSlots + slot;
+    const long bstride = (long)Hp * kSlots;
+    float plain = 0.0f;
+    for (int b = 0; b < B; ++b) plain += src[b * bstride];
+    if (is_g && dWc) dWc[k * in_dim + slot] = plain;
+    if (is_s && dbc) dbc[k] = plain;
+    float* zdst = is_s ? dWz : dWbi;
+    if (!zdst || Zd == 0) return;
+    for (int q0 = 0; q0 < Zd; q0 += kZChunk) {
+        float acc[kZChunk];
+#pragma unroll
+        for (int q = 0; q < kZChunk; ++q) acc[q] = 0.0f;
+        for (int b = 0; b < B; ++b) {
+            const float v = src[b * bstride];
+#pragma unroll
+            for (int q = 0; q < kZChunk; ++q)
+                if (q0 + q < Zd) acc[q] += v * z[(long)b * Zd + q0 + q];
         }
-    if (dWbi)
-        for (int p = 0; p < in_dim; ++p)
-            for (int q = 0; q < Zd; ++q) {
-                float s = 0.0f;
-                for (int b = 0; b < B; ++b) s += sgimg[((long)b * Hp + k) * kSlots + p] * z[(long)b * Zd + q];
-                dWbi[((long)k * in_dim + p) * Zd + q] = s;
+#pragma unroll
+        for (int q = 0; q < kZChunk; ++q)
+            if (q0 + q < Zd) {
+                if (is_s) dWz[(long)k * Zd + q0 + q] = acc[q];
+                else dWbi[((long)k * in_dim + slot) * Zd + q0 + q] = acc[q];
             }
+    }
 }
 
 // (d) dz[b][q] = sum_k S_b[k] W_z[k][q] + sum_{k,p} G_b[k][p] W_bi[k][p][q]   (one block per image)

@@ -57,13 +57,13 @@ def main():
     for _ in range(3):
         it()
     torch.cuda.synchronize()
-    _lib.profile_enable(True)
+    _lib.profile_enable(2)
     _lib.profile_read()
     for _ in range(args.iters):
         it()
     torch.cuda.synchronize()
     prof = _lib.profile_read()
-    _lib.profile_enable(False)
+    _lib.profile_enable(0)
     M = args.B * N
     gf = 2.0 * M * args.H * args.H / 1e9
     for k, (ms, cnt) in sorted(prof.items()):
