@@ -170,6 +170,32 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
                          void* ws, size_t ws_bytes, svae_stream_t stream);
 
 /*
+ * Latent head of eval_minibatch: reparameterisation, pose split and the KL terms, per image.  Replaces
+ * train_mnist.py:33-39 (z = exp(logstd)*r + mu), :42-53 / :65-72 (theta = z[:,0]; dx = z[:,off:off+2]*dx_scale;
+ * content = z[:,c0:], times z_scale in train_galaxy.py:112 / train_particles.py:99), :61-63 (KL of theta;
+ * mu_penalty = 1 keeps train_mnist.py's mu^2 term, 0 is train_galaxy.py:98-99 / train_particles.py:85-86) and
+ * :84-85 (unit-normal KL over every remaining latent).  kl[b] is the per-image KL; the reference's kl_div is its mean.
+ *   q_out (B, 2*inf_dim) = [z_mu | z_logstd] as InferenceNetwork produces it (models.py:50-52); r (B, inf_dim)
+ *   theta (B) iff rotate; dx (B, 2) iff translate; zc (B, inf_dim - rotate - 2*translate) iff non-empty; kl (B)
+ * Backward: g_* are d(loss)/d(output) (NULL = zero); g_q_out (B, 2*inf_dim) is overwritten.
+ */
+typedef struct svae_latent_desc {
+    int32_t B;
+    int32_t inf_dim;
+    int32_t rotate;
+    int32_t translate;
+    int32_t mu_penalty;
+    float dx_scale;
+    float z_scale;
+    float theta_prior;
+} svae_latent_desc;
+int svae_latent_forward(const svae_latent_desc* d, const float* q_out, const float* r, float* theta, float* dx,
+                        float* zc, float* kl, svae_stream_t stream);
+int svae_latent_backward(const svae_latent_desc* d, const float* q_out, const float* r, const float* g_theta,
+                         const float* g_dx, const float* g_zc, const float* g_kl, float* g_q_out,
+                         svae_stream_t stream);
+
+/*
  * Optional per-kernel timing (bench.py's roofline figure).  While enabled (on = 1: only the three MFMA
  * GEMM kernels, on = 2: every kernel, 0 = off), kernel launches of
  * this library are bracketed by two HIP events recorded on the launch stream; svae_profile_read

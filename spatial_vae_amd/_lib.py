@@ -16,7 +16,7 @@ FLAG_RESID, FLAG_BILINEAR, FLAG_SOFTPLUS = 1, 2, 4
 EXPORTS = ("svae_abi_version", "svae_last_error", "svae_saved_bytes", "svae_workspace_bytes",
            "svae_decoder_forward", "svae_decoder_backward", "svae_bce_loglik",
            "svae_gaussian_workspace_bytes", "svae_gaussian_loglik", "svae_profile_enable", "svae_profile_read",
-           "svae_profile_kind_name")
+           "svae_profile_kind_name", "svae_latent_forward", "svae_latent_backward")
 PROF_KINDS = 16
 
 
@@ -33,6 +33,12 @@ class Params(ctypes.Structure):
 class Pose(ctypes.Structure):
     _fields_ = [("coords", ctypes.c_void_p), ("grid", ctypes.c_void_p), ("theta", ctypes.c_void_p),
                 ("dx", ctypes.c_void_p)]
+
+
+class LatentDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("inf_dim", ctypes.c_int32), ("rotate", ctypes.c_int32),
+                ("translate", ctypes.c_int32), ("mu_penalty", ctypes.c_int32), ("dx_scale", ctypes.c_float),
+                ("z_scale", ctypes.c_float), ("theta_prior", ctypes.c_float)]
 
 
 class PoseGrads(ctypes.Structure):
@@ -72,6 +78,10 @@ def lib():
     L.svae_gaussian_workspace_bytes.argtypes = [i32, i32]
     L.svae_gaussian_loglik.restype = ctypes.c_int
     L.svae_gaussian_loglik.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, sz, vp]
+    L.svae_latent_forward.restype = ctypes.c_int
+    L.svae_latent_forward.argtypes = [ctypes.POINTER(LatentDesc), vp, vp, vp, vp, vp, vp, vp]
+    L.svae_latent_backward.restype = ctypes.c_int
+    L.svae_latent_backward.argtypes = [ctypes.POINTER(LatentDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     L.svae_profile_enable.restype = ctypes.c_int
     L.svae_profile_enable.argtypes = [ctypes.c_int]
     L.svae_profile_read.restype = ctypes.c_int

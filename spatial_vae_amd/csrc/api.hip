@@ -55,6 +55,8 @@ struct Plan {
     float* sgpart;
     float* sgimg;
     float* dcoords;
+    float* sgtile;  // fused first-layer backward: per-tile sums (tiles x 2 x Hp x 4)
+    float* dfpart;  // fused first-layer backward: per-column-block d(coords) (ntile x Mp x 2)
     // split geometry
     int wg_nblk1, wg_S;
     long ob_oct_per_chunk;
@@ -116,6 +118,8 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.sgpart = cw.take<float>((size_t)g.B * p.l0_chunks_per_image * g.Hp * 2 * kSlots);
     p.sgimg = cw.take<float>((size_t)g.B * g.Hp * kSlots);
     p.dcoords = cw.take<float>((size_t)g.B * g.N * 2);
+    p.sgtile = cw.take<float>((size_t)g.tiles * 2 * g.Hp * 4);
+    p.dfpart = cw.take<float>((size_t)g.ntile * g.Mp * 2);
     p.ws_bytes = (cw.off + 255) & ~size_t(255);
     return p;
 }
@@ -157,10 +161,10 @@ int check_ws(const Plan& p, const void* ws, size_t ws_bytes) {
 
 // ---- opt-in per-kernel timing with HIP events (svae_profile_*)
 enum Kind { K_PREPARE = 0, K_LAYER0_FWD, K_DENSE_FWD, K_OUT_FWD, K_DLOGITS, K_OUT_BWD, K_WGRAD, K_WGRAD_REDUCE,
-            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_COUNT };
+            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_COUNT };
 const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense_fwd", "out_fwd", "dlogits", "out_bwd",
                                                  "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
-                                                 "gaussian", "", "", ""};
+                                                 "gaussian", "latent", "", ""};
 struct ProfRec { hipEvent_t a, b; int kind; };
 std::mutex g_prof_mu;
 int g_prof_level = 0;  // 0 off, 1 = the three MFMA GEMM kernels only, 2 = every kernel
@@ -227,21 +231,26 @@ void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const Po
                            pl.wf[l], pl.wb[l], g.H, g.Hp);
 }
 
-template <int NT, bool DGRAD, bool RESID>
+template <int NT, bool DGRAD, bool RESID, bool FIRST>
 void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
     static bool attr_set = false;  // LDS beyond 64 KiB needs the opt-in attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID, FIRST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, DenseCfg<NT>::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID>), grid, dim3(256), DenseCfg<NT>::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID, FIRST>), grid, dim3(256), DenseCfg<NT>::LDS_BYTES, st, a);
 }
 
 template <int NT, bool DGRAD>
-void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st) {
-    if (a.resid) launch_dense_ntr<NT, DGRAD, true>(a, grid, st);
-    else launch_dense_ntr<NT, DGRAD, false>(a, grid, st);
+void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false) {
+    if (DGRAD && first) {
+        if (a.resid) launch_dense_ntr<NT, true, true, true>(a, grid, st);
+        else launch_dense_ntr<NT, true, false, true>(a, grid, st);
+    } else {
+        if (a.resid) launch_dense_ntr<NT, DGRAD, true, false>(a, grid, st);
+        else launch_dense_ntr<NT, DGRAD, false, false>(a, grid, st);
+    }
 }
 
 // column tiles accumulated per pass: the widest that divides the layer, unless SVAE_DENSE_NT caps it
@@ -256,17 +265,25 @@ int dense_nt_for(int ntile) {
     return nt;
 }
 
+// the fused first-layer epilogue keeps 64 extra values per lane: it runs with half the column tiles
+int dense_nt_first(int ntile) {
+    int nt = dense_nt_for(ntile);
+    static const int cap = [] { const char* e = getenv("SVAE_FIRST_NT"); return e ? atoi(e) : 4; }();
+    while (nt > cap && nt > 1) nt >>= 1;
+    return nt;
+}
+
 template <bool DGRAD>
-void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st) {
+void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
-    const int nt = dense_nt_for(g.ntile);
+    const int nt = first ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
     switch (nt) {
-        case 16: launch_dense_nt<16, DGRAD>(a, grid, st); break;
-        case 8: launch_dense_nt<8, DGRAD>(a, grid, st); break;
-        case 4: launch_dense_nt<4, DGRAD>(a, grid, st); break;
-        case 2: launch_dense_nt<2, DGRAD>(a, grid, st); break;
-        default: launch_dense_nt<1, DGRAD>(a, grid, st); break;
+        case 16: launch_dense_nt<16, DGRAD>(a, grid, st, first); break;
+        case 8: launch_dense_nt<8, DGRAD>(a, grid, st, first); break;
+        case 4: launch_dense_nt<4, DGRAD>(a, grid, st, first); break;
+        case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first); break;
+        default: launch_dense_nt<1, DGRAD>(a, grid, st, first); break;
     }
 }
 
@@ -355,6 +372,8 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
         a.H = g.H;
         a.act = g.act;
         a.resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
+        a.pose = pa; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr; a.dfpart = nullptr;
+        a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
         launch_dense<false>(g, a, st);
     }
     switch (g.C) {
@@ -409,6 +428,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     }
 
     // hidden layers, last to first
+    bool fused_first = false;
     for (int l = g.L - 1; l >= 1; --l) {
         if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1]) {
             WgradArgs w;
@@ -444,36 +464,50 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         a.H = g.H;
         a.act = g.act;
         a.resid = resid;
-        launch_dense<true>(g, a, st);
+        a.pose = pa; a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile; a.dfpart = pl.dfpart;
+        a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
+        fused_first = (l == 1) && g.in_dim == 2;
+        launch_dense<true>(g, a, st, fused_first);
         cur ^= 1;
     }
 
     // coordinate layer
-    const float* dh0 = pl.dh[cur];
-    Scope prof_l0(K_LAYER0_BWD, st);
-    hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0, st,
-                       pa, pl.posebuf, dh0, pl.sgpart, row_geo(g), pl.l0_oct_per_chunk, pl.l0_chunks_per_image);
-    hipLaunchKernelGGL(sg_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp * kSlots)), dim3(256), 0, st, pl.sgpart, pl.sgimg,
-                       g.B, g.Hp, pl.l0_chunks_per_image);
     const bool bil = (g.flags & SVAE_FLAG_BILINEAR) != 0;
-    hipLaunchKernelGGL(layer0_param_grads_kernel, dim3(blocks_for((long)g.H * kSlots)), dim3(256), 0, st, pl.sgimg, z, grads->coord_w,
-                       grads->coord_b, g.Zd > 0 ? grads->latent_w : nullptr, bil ? grads->bilinear_w : nullptr, g.B, g.H,
-                       g.Hp, g.Zd, g.in_dim);
-    if (dz && g.Zd > 0)
-        hipLaunchKernelGGL(dz_kernel, dim3(g.B), dim3(256), 0, st, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr, dz,
-                           g.H, g.Hp, g.Zd, g.in_dim);
-
-    if (pg && (pg->dcoords || pg->dtheta || pg->ddx)) {
-        float* dc = pg->dcoords ? pg->dcoords : pl.dcoords;
-        long nb = (g.noct + 3) / 4;
-        if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(layer0_bwd_coords_kernel, dim3((unsigned)nb), dim3(256), 0, st, pa, pl.posebuf, dh0, pl.tab, dc,
-                           row_geo(g), g.noct);
-        if (pg->dtheta || pg->ddx) {
-            if (pose->coords) return fail(SVAE_E_INVALID, "dtheta/ddx requested but the pose was given as explicit coords");
+    const bool want_coords = pg && (pg->dcoords || pg->dtheta || pg->ddx);
+    if (want_coords && (pg->dtheta || pg->ddx) && pose->coords)
+        return fail(SVAE_E_INVALID, "dtheta/ddx requested but the pose was given as explicit coords");
+    float* dc = (pg && pg->dcoords) ? pg->dcoords : pl.dcoords;
+    {
+        Scope prof_l0(K_LAYER0_BWD, st);
+        if (fused_first) {
+            // dh0 was reduced inside the data-gradient GEMM's epilogue: only small fixed-order sums remain
+            hipLaunchKernelGGL(sgtile_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp)), dim3(256), 0, st, pl.sgtile, pl.sgimg,
+                               g.B, g.Hp, g.Timg);
+            if (want_coords)
+                hipLaunchKernelGGL(coords_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, dc,
+                                   g.ntile / dense_nt_first(g.ntile), g.B, g.N, g.Npad, (long)g.Mp);
+        } else {
+            const float* dh0 = pl.dh[cur];
+            hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0,
+                               st, pa, pl.posebuf, dh0, pl.sgpart, row_geo(g), pl.l0_oct_per_chunk, pl.l0_chunks_per_image);
+            hipLaunchKernelGGL(sg_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp * kSlots)), dim3(256), 0, st, pl.sgpart,
+                               pl.sgimg, g.B, g.Hp, pl.l0_chunks_per_image);
+            if (want_coords) {
+                long nb = (g.noct + 3) / 4;
+                if (nb > 4096) nb = 4096;
+                hipLaunchKernelGGL(layer0_bwd_coords_kernel, dim3((unsigned)nb), dim3(256), 0, st, pa, pl.posebuf, dh0, pl.tab,
+                                   dc, row_geo(g), g.noct);
+            }
+        }
+        hipLaunchKernelGGL(layer0_param_grads_kernel, dim3((unsigned)(((long)g.H * kSlots + 31) / 32)), dim3(256), 0, st,
+                           pl.sgimg, z, grads->coord_w, grads->coord_b, g.Zd > 0 ? grads->latent_w : nullptr,
+                           bil ? grads->bilinear_w : nullptr, g.B, g.H, g.Hp, g.Zd, g.in_dim);
+        if (dz && g.Zd > 0)
+            hipLaunchKernelGGL(dz_kernel, dim3(g.B), dim3(256), 0, st, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr,
+                               dz, g.H, g.Hp, g.Zd, g.in_dim);
+        if (want_coords && (pg->dtheta || pg->ddx))
             hipLaunchKernelGGL(pose_bwd_kernel, dim3(g.B), dim3(256), 0, st, dc, pose->grid, pl.posebuf, pg->dtheta, pg->ddx,
                                g.N);
-        }
     }
     return launch_status("svae_decoder_backward");
 }
@@ -513,6 +547,42 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
     hipLaunchKernelGGL(gaussian_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), y_params, target, mask, ctf,
                        k, loglik, dll_dy, filt, dflt, N, C);
     return launch_status("svae_gaussian_loglik");
+}
+
+static int latent_geo(const svae_latent_desc* d, LatentGeo* g) {
+    if (!d || d->B < 1 || d->inf_dim < 1) return fail(SVAE_E_INVALID, "svae_latent: bad descriptor");
+    if (d->inf_dim < (d->rotate ? 1 : 0) + (d->translate ? 2 : 0))
+        return fail(SVAE_E_INVALID, "svae_latent: inf_dim %d too small for the requested pose", d->inf_dim);
+    g->B = d->B; g->inf = d->inf_dim; g->rotate = d->rotate ? 1 : 0; g->translate = d->translate ? 1 : 0;
+    g->mu_penalty = d->mu_penalty ? 1 : 0; g->dx_scale = d->dx_scale; g->z_scale = d->z_scale; g->theta_prior = d->theta_prior;
+    return SVAE_OK;
+}
+
+int svae_latent_forward(const svae_latent_desc* d, const float* q_out, const float* r, float* theta, float* dx, float* zc,
+                        float* kl, svae_stream_t stream) {
+    LatentGeo g;
+    int rc;
+    if ((rc = latent_geo(d, &g))) return rc;
+    const int zd = g.inf - g.rotate - 2 * g.translate;
+    if (!q_out || !r || !kl || (g.rotate && !theta) || (g.translate && !dx) || (zd > 0 && !zc))
+        return fail(SVAE_E_INVALID, "svae_latent_forward: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_LATENT, st);
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(blocks_for(g.B)), dim3(256), 0, st, q_out, r, theta, dx, zc, kl, g);
+    return launch_status("svae_latent_forward");
+}
+
+int svae_latent_backward(const svae_latent_desc* d, const float* q_out, const float* r, const float* g_theta,
+                         const float* g_dx, const float* g_zc, const float* g_kl, float* g_q_out, svae_stream_t stream) {
+    LatentGeo g;
+    int rc;
+    if ((rc = latent_geo(d, &g))) return rc;
+    if (!q_out || !r || !g_q_out) return fail(SVAE_E_INVALID, "svae_latent_backward: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_LATENT, st);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(blocks_for((long)g.B * g.inf)), dim3(256), 0, st, q_out, r, g_theta, g_dx,
+                       g_zc, g_kl, g_q_out, g);
+    return launch_status("svae_latent_backward");
 }
 
 int svae_profile_enable(int on) {

@@ -122,6 +122,12 @@ __device__ __forceinline__ void image_pose(const PoseArgs& p, int b, float& c, f
     }
 }
 
+// coordinates of padded row i of image b; pad rows (i >= N) read as (0, 0)
+__device__ __forceinline__ float2 row_coord(const PoseArgs& pose, const float4 pb, int b, int i, int N) {
+    if (i >= N) return make_float2(0.0f, 0.0f);
+    return pixel_coord(pose, b, i, N, pb.x, pb.y, pb.z, pb.w);
+}
+
 // [x0, x1, x0^2, x1^2, x0*x1] (models.py:99-102); only the first in_dim entries are used
 __device__ __forceinline__ void coord_feats(float2 x, float f[5]) {
     f[0] = x.x; f[1] = x.y; f[2] = x.x * x.x; f[3] = x.y * x.y; f[4] = x.x * x.y;
@@ -135,7 +141,6 @@ __device__ __forceinline__ float wave_sum32(float v) {  // sum over the 32 lanes
     v += __shfl_xor(v, 16);
     return v;
 }
-__device__ __forceinline__ float wave_sum64(float v) { return wave_sum32(v) + __shfl_xor(wave_sum32(v), 32); }
 
 // sum over a 256-thread block; result valid in every thread.  red must hold 4 floats.
 __device__ __forceinline__ float block_sum256(float v, float* red) {

@@ -40,6 +40,16 @@ struct DenseArgs {
     int H;
     int act;
     int resid;
+    // FIRST (data gradient into the coordinate layer, in_dim == 2): instead of storing dh0 the epilogue
+    // reduces it on the spot -- over the tile's rows into (G0, G1, S) per feature, over this block's
+    // features into d(coords) per row (dW_c, db_c, dW_z, dz, dtheta, ddx all derive from these)
+    PoseArgs pose;
+    const float4* posebuf;  // (B) cos, sin, dx0, dx1
+    const float* tab;       // (B, Hp, 8) effective first-layer weights, slots 0,1 used here
+    float* sgtile;          // [tiles][2][Hp][4] = (G0, G1, S, -)
+    float* dfpart;          // [Hp/NB][Mp][2]
+    long Mp;
+    int N, Timg;
 };
 
 template <int ACT, bool DGRAD>
@@ -131,8 +141,9 @@ struct DenseCfg {
     static constexpr int NINSTR = G * NT;              // 1 KiB global_load_lds wave-instructions per chunk
 };
 
-template <int NT, bool DGRAD, bool RESID>
+template <int NT, bool DGRAD, bool RESID, bool FIRST = false>
 __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArgs a) {
+    static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using Cfg = DenseCfg<NT>;
     constexpr int NB = Cfg::NB, G = Cfg::G, CHUNK = Cfg::CHUNK, NINSTR = Cfg::NINSTR;
@@ -294,11 +305,91 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
                         *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = v;
                     }
                 };
-                if (DGRAD || RESID) fetch(0, xa[0], xr[0]);
+                if (!FIRST) {
+                    if (DGRAD || RESID) fetch(0, xa[0], xr[0]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if ((DGRAD || RESID) && t + 1 < NT) fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
-                    finish(t, xa[t & 1], xr[t & 1]);
+                    for (int t = 0; t < NT; ++t) {
+                        if ((DGRAD || RESID) && t + 1 < NT) fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
+                        finish(t, xa[t & 1], xr[t & 1]);
+                    }
+                } else {
+                    // coordinates of this lane's 16 rows (row 8q + 4h + r of the tile), wave-uniform image
+                    const int b = (int)(tl / a.Timg);
+                    const int i0 = (int)(tl % a.Timg) * 32 + 4 * h;
+                    const float4 pb = a.posebuf[b];  // identity (1, 0, 0, 0) when the coordinates are explicit
+                    const float* cbase = a.pose.coords ? a.pose.coords + (long)b * a.N * 2 : a.pose.grid;
+                    float2 raw[16];
+                    float x0[16], x1[16], pd0[16], pd1[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)  // 16 independent loads, no branches: pad rows re-read row N-1
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = i0 + 8 * q + r;
+                            raw[4 * q + r] = *reinterpret_cast<const float2*>(cbase + (long)(i < a.N ? i : a.N - 1) * 2);
+                        }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = 4 * q + r;
+                            const bool in = i0 + 8 * q + r < a.N;
+                            const float2 g2 = raw[idx];
+                            x0[idx] = in ? pb.x * g2.x - pb.y * g2.y + pb.z : 0.0f;
+                            x1[idx] = in ? pb.y * g2.x + pb.x * g2.y + pb.w : 0.0f;
+                            pd0[idx] = 0.0f; pd1[idx] = 0.0f;
+                        }
+                    float2 tk[2];
+                    auto fetch_tab = [&](int t) {
+                        const int k = nb * NB + t * 32 + nl;
+                        return *reinterpret_cast<const float2*>(a.tab + ((long)b * Hp + k) * kSlots);
+                    };
+                    fetch(0, xa[0], xr[0]);
+                    tk[0] = fetch_tab(0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (t + 1 < NT) {
+                            fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
+                            tk[(t + 1) & 1] = fetch_tab(t + 1);
+                        }
+                        float sv = 0.0f, g0 = 0.0f, g1 = 0.0f;
+                        const float2 w = tk[t & 1];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float4 v = make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+                            if (RESID) {
+                                const float4 fr = xr[t & 1][q];
+                                v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
+                            }
+                            v = dense_epilogue<ACT, true>(v, 0.0f, xa[t & 1][q]);
+                            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                sv += vv[r];
+                                g0 += vv[r] * x0[4 * q + r];
+                                g1 += vv[r] * x1[4 * q + r];
+                                pd0[4 * q + r] += vv[r] * w.x;
+                                pd1[4 * q + r] += vv[r] * w.y;
+                            }
+                        }
+                        const int k = nb * NB + t * 32 + nl;
+                        *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) = make_float4(g0, g1, sv, 0.0f);
+                    }
+                    // d(coords) of each row: sum this block's NB features = over the tiles (done) and the 32 lanes
+#pragma unroll
+                    for (int idx = 0; idx < 16; ++idx) {
+                        pd0[idx] = wave_sum32(pd0[idx]);
+                        pd1[idx] = wave_sum32(pd1[idx]);
+                    }
+                    if (nl == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const long m = tl * 32 + 8 * q + 4 * h + r;
+                                *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) =
+                                    make_float2(pd0[4 * q + r], pd1[4 * q + r]);
+                            }
+                    }
                 }
             };
             switch (a.act) {

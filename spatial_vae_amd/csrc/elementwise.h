@@ -64,11 +64,6 @@ struct RowGeo {
     int N, Npad, Hp, in_dim, act, B;
 };
 
-__device__ __forceinline__ float2 row_coord(const PoseArgs& pose, const float4 pb, int b, int i, int N) {
-    if (i >= N) return make_float2(0.0f, 0.0f);
-    return pixel_coord(pose, b, i, N, pb.x, pb.y, pb.z, pb.w);
-}
-
 // ---------------------------------------------------------------- coordinate layer, forward
 // a0[m][k] = act( sum_p feat_p(x''_m) tab[b][k][p] + tab[b][k][5] ): thread = (octet, k, half)
 // computes four consecutive rows and stores them as one 16-byte vector; the thread index IS the
@@ -340,43 +335,92 @@ __global__ void layer0_bwd_coords_kernel(PoseArgs pose, const float4* __restrict
     }
 }
 
-// (c) first-layer parameter gradients from the per-image sums.  Thread = (k, slot): consecutive threads
-//     read consecutive floats of sgimg[b], so each of the B passes is one coalesced sweep.
+// (a') fused path: the data-gradient GEMM of the first hidden layer already reduced dh0 over each 32-row tile
+//      (dense_kernel<.., FIRST>): sgtile[tile][half][k] = (G0, G1, S, -).  Sum the tiles and halves of each image.
+__global__ void sgtile_reduce_kernel(const float* __restrict__ sgtile, float* __restrict__ sgimg, int B, int Hp, int Timg) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*Hp
+    if (idx >= (long)B * Hp) return;
+    const int k = idx % Hp, b = idx / Hp;
+    float g0 = 0.0f, g1 = 0.0f, sv = 0.0f;
+    for (int t = 0; t < Timg; ++t)
+        for (int h = 0; h < 2; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(sgtile + ((((long)b * Timg + t) * 2 + h) * Hp + k) * 4);
+            g0 += v.x; g1 += v.y; sv += v.z;
+        }
+    float4* dst = reinterpret_cast<float4*>(sgimg + idx * kSlots);
+    dst[0] = make_float4(g0, g1, 0.0f, 0.0f);
+    dst[1] = make_float4(0.0f, sv, 0.0f, 0.0f);
+}
+
+// (b') fused path: d(coords)[b][i] = sum over column blocks of dfpart[block][mp] (in_dim == 2: dfeat = dcoords)
+__global__ void coords_finish_kernel(const float* __restrict__ dfpart, float* __restrict__ dcoords, int nblocks, int B,
+                                     int N, int Npad, long Mp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*N
+    if (idx >= (long)B * N) return;
+    const int i = idx % N, b = idx / N;
+    const long mp = (long)b * Npad + i;
+    float d0 = 0.0f, d1 = 0.0f;
+    for (int nb = 0; nb < nblocks; ++nb) {
+        const float2 v = *reinterpret_cast<const float2*>(dfpart + ((long)nb * Mp + mp) * 2);
+        d0 += v.x; d1 += v.y;
+    }
+    *reinterpret_cast<float2*>(dcoords + idx * 2) = make_float2(d0, d1);
+}
+
+// (c) first-layer parameter gradients from the per-image sums.  A block owns 32 consecutive (k, slot)
+//     columns of sgimg; thread = (column, image lane): 8 interleaved partial sums over the images per
+//     column (coalesced 128-byte sweeps), combined in LDS in a fixed order.
 //     dW_c[k][p] = sum_b G_b[k][p];  db_c[k] = sum_b S_b[k];  dW_z[k][q] = sum_b S_b[k] z[b][q];
 //     dW_bi[k][p][q] = sum_b G_b[k][p] z[b][q]
-constexpr int kZChunk = 16;
+constexpr int kZChunk = 8;
 __global__ void layer0_param_grads_kernel(const float* __restrict__ sgimg, const float* __restrict__ z,
                                           float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWz,
                                           float* __restrict__ dWbi, int B, int H, int Hp, int Zd, int in_dim) {
-    const int t = blockIdx.x * 256 + threadIdx.x;  // over H * kSlots
-    if (t >= H * kSlots) return;
-    const int k = t / kSlots, slot = t % kSlots;
-    const bool is_g = slot < in_dim, is_s = slot == kBiasSlot;
-    if (!is_g && !is_s) return;
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + col;  // over H * kSlots
+    const bool in_range = t < H * kSlots;
+    const int k = in_range ? t / kSlots : 0, slot = in_range ? t % kSlots : 0;
+    const bool is_g = in_range && slot < in_dim, is_s = in_range && slot == kBiasSlot;
     const float* src = sgimg + (long)k * kSlots + slot;
     const long bstride = (long)Hp * kSlots;
+    auto combine = [&](float v) {  // fixed-order sum of the 8 image lanes of this column; valid where bl == 0
+        __syncthreads();
+        red[bl][col] = v;
+        __syncthreads();
+        float r = red[0][col];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) r += red[j][col];
+        return r;
+    };
     float plain = 0.0f;
-    for (int b = 0; b < B; ++b) plain += src[b * bstride];
-    if (is_g && dWc) dWc[k * in_dim + slot] = plain;
-    if (is_s && dbc) dbc[k] = plain;
-    float* zdst = is_s ? dWz : dWbi;
-    if (!zdst || Zd == 0) return;
-    for (int q0 = 0; q0 < Zd; q0 += kZChunk) {
+    if (is_g || is_s)
+        for (int b = bl; b < B; b += 8) plain += src[b * bstride];
+    plain = combine(plain);
+    if (bl == 0) {
+        if (is_g && dWc) dWc[k * in_dim + slot] = plain;
+        if (is_s && dbc) dbc[k] = plain;
+    }
+    const bool want_z = (is_s && dWz) || (is_g && dWbi);
+    for (int q0 = 0; q0 < Zd; q0 += kZChunk) {  // uniform trip count: combine() holds barriers
         float acc[kZChunk];
 #pragma unroll
         for (int q = 0; q < kZChunk; ++q) acc[q] = 0.0f;
-        for (int b = 0; b < B; ++b) {
-            const float v = src[b * bstride];
+        if (want_z)
+            for (int b = bl; b < B; b += 8) {
+                const float v = src[b * bstride];
 #pragma unroll
-            for (int q = 0; q < kZChunk; ++q)
-                if (q0 + q < Zd) acc[q] += v * z[(long)b * Zd + q0 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < kZChunk; ++q)
-            if (q0 + q < Zd) {
-                if (is_s) dWz[(long)k * Zd + q0 + q] = acc[q];
-                else dWbi[((long)k * in_dim + slot) * Zd + q0 + q] = acc[q];
+                for (int q = 0; q < kZChunk; ++q)
+                    if (q0 + q < Zd) acc[q] += v * z[(long)b * Zd + q0 + q];
             }
+#pragma unroll
+        for (int q = 0; q < kZChunk; ++q) {
+            const float r = combine(acc[q]);
+            if (bl == 0 && want_z && q0 + q < Zd) {
+                if (is_s) dWz[(long)k * Zd + q0 + q] = r;
+                else dWbi[((long)k * in_dim + slot) * Zd + q0 + q] = r;
+            }
+        }
     }
 }
 
@@ -523,6 +567,66 @@ __global__ void gaussian_kernel(const float* __restrict__ yp, const float* __res
             dll[(long)b * N * C + j] = s;
         }
     }
+}
+
+// ---------------------------------------------------------------- A7: latent head (reparameterise, split, KL)
+struct LatentGeo {
+    int B, inf, rotate, translate, mu_penalty;
+    float dx_scale, z_scale, theta_prior;
+};
+
+// one thread per image: z = exp(logstd)*r + mu; theta / dx / content; kl[b]
+__global__ void latent_fwd_kernel(const float* __restrict__ q, const float* __restrict__ r, float* __restrict__ theta,
+                                  float* __restrict__ dx, float* __restrict__ zc, float* __restrict__ kl, LatentGeo g) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= g.B) return;
+    const float* mu = q + (long)b * 2 * g.inf;
+    const float* ls = mu + g.inf;
+    const int off = g.rotate ? 1 : 0, c0 = off + (g.translate ? 2 : 0), zd = g.inf - c0;
+    float k = 0.0f;
+    for (int j = 0; j < g.inf; ++j) {
+        const float sd = expf(ls[j]);
+        const float z = sd * r[(long)b * g.inf + j] + mu[j];
+        if (j < off) {
+            theta[b] = z;
+            const float s = g.theta_prior;
+            k += -ls[j] + logf(s) + (sd * sd + (g.mu_penalty ? mu[j] * mu[j] : 0.0f)) / 2.0f / (s * s) - 0.5f;
+        } else {
+            k += -ls[j] + 0.5f * sd * sd + 0.5f * mu[j] * mu[j] - 0.5f;
+            if (j < c0) dx[2 * b + (j - off)] = z * g.dx_scale;
+            else zc[(long)b * zd + (j - c0)] = z * g.z_scale;
+        }
+    }
+    kl[b] = k;
+}
+
+// one thread per (image, latent): d(loss)/d(mu), d(loss)/d(logstd)
+__global__ void latent_bwd_kernel(const float* __restrict__ q, const float* __restrict__ r,
+                                  const float* __restrict__ g_theta, const float* __restrict__ g_dx,
+                                  const float* __restrict__ g_zc, const float* __restrict__ g_kl, float* __restrict__ gq,
+                                  LatentGeo g) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)g.B * g.inf) return;
+    const int j = idx % g.inf, b = idx / g.inf;
+    const float* mu = q + (long)b * 2 * g.inf;
+    const float* ls = mu + g.inf;
+    const int off = g.rotate ? 1 : 0, c0 = off + (g.translate ? 2 : 0), zd = g.inf - c0;
+    const float sd = expf(ls[j]);
+    const float gk = g_kl ? g_kl[b] : 0.0f;
+    float dz, dmu, dls;
+    if (j < off) {
+        const float s2 = g.theta_prior * g.theta_prior;
+        dz = g_theta ? g_theta[b] : 0.0f;
+        dmu = g.mu_penalty ? gk * mu[j] / s2 : 0.0f;
+        dls = gk * (-1.0f + sd * sd / s2);
+    } else {
+        if (j < c0) dz = g_dx ? g_dx[2 * b + (j - off)] * g.dx_scale : 0.0f;
+        else dz = g_zc ? g_zc[(long)b * zd + (j - c0)] * g.z_scale : 0.0f;
+        dmu = gk * mu[j];
+        dls = gk * (-1.0f + sd * sd);
+    }
+    gq[(long)b * 2 * g.inf + j] = dz + dmu;
+    gq[(long)b * 2 * g.inf + g.inf + j] = dz * r[idx] * sd + dls;
 }
 
 }  // namespace svae

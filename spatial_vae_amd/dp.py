@@ -43,20 +43,46 @@ def shard_bounds(n, rank, world):
 
 
 class FlatGrads(object):
-    """Owns one flat fp32 buffer; every parameter's .grad is a view into it."""
+    """One flat fp32 gradient buffer (and optionally one flat parameter buffer) for a set of parameters.
 
-    def __init__(self, params):
+    * every parameter's storage is re-pointed into `flat_param` (p.data becomes a view), so a single
+      fused Adam update over one tensor steps all of them;
+    * gradients live in `flat`: parameters in `sinks` (the decoder's, whose backward kernels take an
+      output pointer) get their view handed to the kernels and are written in place -- their .grad stays
+      None until autograd assigns that very view, no accumulate kernel runs; every other parameter's
+      .grad IS its view and autograd accumulates into it in place.
+    """
+
+    def __init__(self, params, sink_params=None, flatten_params=False):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        self.flat_param = None
+        sink_ids = {id(p): name for name, p in (sink_params or {}).items()}
+        self.sinks = {}
+        self._sink_list = []
+        if flatten_params:
+            self.flat_param = torch.empty(n, dtype=torch.float32, device=ref.device)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            view = self.flat[off:off + p.numel()].view_as(p)
+            if flatten_params:
+                pv = self.flat_param[off:off + p.numel()].view_as(p)
+                pv.copy_(p.data)
+                p.data = pv
+            if id(p) in sink_ids:
+                self.sinks[sink_ids[id(p)]] = view
+                self._sink_list.append(p)
+                p.grad = None
+            else:
+                p.grad = view
             off += p.numel()
 
     def zero(self):
         self.flat.zero_()
+        for p in self._sink_list:
+            p.grad = None
 
     def all_reduce(self, weight=1.0):
         """flat <- sum over ranks of weight * flat (weight = local_count / global_count)."""
@@ -72,6 +98,8 @@ class TrainStep(object):
     Mirrors the loop body of train_epoch (/root/reference/train_mnist.py:143-150):
     loss = -elbo; backward; optim.step; optim.zero_grad -- with the zeroing done on the flat
     buffer and the metrics left on the device (the caller decides when to pay for .item()).
+    torch.optim.Adam is unchanged; it simply sees ONE parameter (the flat buffer every module
+    parameter is a view of), which is the same element-wise update in one kernel.
     """
 
     def __init__(self, p_net, q_net, eval_minibatch, lr=1e-4, fused_adam=None, **eval_kwargs):
@@ -79,12 +107,17 @@ class TrainStep(object):
         self.eval_minibatch = eval_minibatch
         self.eval_kwargs = eval_kwargs
         params = list(p_net.parameters()) + list(q_net.parameters())
-        self.grads = FlatGrads(params)
         on_gpu = params[0].is_cuda
+        sink_params = p_net.decoder_parameters() if (on_gpu and hasattr(p_net, "decoder_parameters")) else None
+        self.grads = FlatGrads(params, sink_params=sink_params, flatten_params=True)
+        if sink_params:
+            p_net._grad_sinks = self.grads.sinks
+        self.master = torch.nn.Parameter(self.grads.flat_param)
+        self.master.grad = self.grads.flat
         if fused_adam is None:
             fused_adam = on_gpu
         kw = {"fused": True} if fused_adam else {}
-        self.optim = torch.optim.Adam(params, lr=lr, **kw)
+        self.optim = torch.optim.Adam([self.master], lr=lr, **kw)
 
     def __call__(self, x, *batch, weight=1.0, **kw):
         args = dict(self.eval_kwargs)

@@ -4,9 +4,9 @@
   eval_minibatch_galaxy     <- /root/reference/train_galaxy.py:27-128
   eval_minibatch_particles  <- /root/reference/train_particles.py:22-148
 
-Same positional arguments and return tuples.  The encoder call, the reparameterisation and the
-(B, inf_dim)-sized KL terms are a handful of tiny torch ops; everything that touches B*N rows --
-pose, decoder, log-likelihood -- goes through the HIP library (ops.py).  Differences from the
+Same positional arguments and return tuples.  The encoder is the caller's torch module; from its output
+onward everything -- reparameterisation, pose split and KL terms (one small kernel), pose, decoder and
+log-likelihood (everything that touches B*N rows) -- goes through the HIP library (ops.py).  Differences from the
 reference, all additive: `noise=` lets a caller supply the N(0,1) draw (parity tests; data-parallel
 runs that slice one global draw), `return_logits=` also returns the pre-Sigmoid output.
 PIL-based rotation augmentation (`augment_rotation`) is host preprocessing outside the hot path
@@ -19,32 +19,25 @@ import torch
 from . import ops
 
 
+def _encode(q_net, y2d):
+    """Raw encoder output [z_mu | z_logstd] (B, 2*inf_dim): InferenceNetwork.forward is layers(x) split in two
+    (models.py:46-54); any other encoder's two outputs are concatenated back."""
+    if hasattr(q_net, "layers") and hasattr(q_net, "latent_dim"):
+        return q_net.layers(y2d)
+    z_mu, z_logstd = q_net(y2d)
+    return torch.cat([z_mu, z_logstd], 1)
+
+
 def _core(script, x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior, z_scale, mask, ctf, noise, use_cuda):
     B = y.size(0)
     if use_cuda:
         y = y.cuda()
-    z_mu, z_logstd = q_net(y.view(B, -1))
-    z_std = torch.exp(z_logstd)
-    inf_dim = z_mu.size(1)
-    # E_q[log p(x|z)] by one reparameterised sample (train_mnist.py:36-39)
-    r = noise if noise is not None else torch.empty(B, inf_dim, device=x.device, dtype=z_mu.dtype).normal_()
-    z = z_std * r + z_mu
-
-    kl = 0
-    theta = None
-    off = 0
-    if rotate:
-        theta = z[:, 0]
-        var_ratio = z_std[:, 0] ** 2
-        if script == "mnist":                       # train_mnist.py:63 penalises the mean too; the others do not
-            var_ratio = var_ratio + z_mu[:, 0] ** 2
-        kl = -z_logstd[:, 0] + math.log(theta_prior) + var_ratio / 2 / theta_prior ** 2 - 0.5
-        off = 1
-    dx = None
-    if translate:
-        dx = z[:, off:off + 2] * dx_scale
-    c0 = off + (2 if translate else 0)
-    zc = z[:, c0:] * z_scale
+    q_out = _encode(q_net, y.view(B, -1))
+    inf_dim = q_out.size(1) // 2
+    # E_q[log p(x|z)] by one reparameterised sample (train_mnist.py:36-39); the draw itself stays a torch call
+    r = noise if noise is not None else torch.empty(B, inf_dim, device=x.device, dtype=q_out.dtype).normal_()
+    # reparameterise + pose split + KL terms in one kernel (train_mnist.py:33-39, 42-72, 61-63, 83-85)
+    theta, dx, zc, kl_b = ops.latent_head(q_out, r, rotate, translate, script == "mnist", dx_scale, z_scale, theta_prior)
 
     if hasattr(p_net, "forward_posed"):
         y_hat, logits = p_net.forward_posed(x, B, theta=theta, dx=dx, z=zc, return_logits=True)
@@ -56,10 +49,7 @@ def _core(script, x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior, 
     else:
         loglik = ops.bce_loglik(y_hat.reshape(B, -1), y.reshape(B, -1))
     log_p_x_g_z = loglik.mean()
-
-    # unit-normal prior on every remaining latent, translation included (train_mnist.py:83-86)
-    z_kl = -z_logstd[:, off:] + 0.5 * z_std[:, off:] ** 2 + 0.5 * z_mu[:, off:] ** 2 - 0.5
-    kl_div = (kl + z_kl.sum(1)).mean()
+    kl_div = kl_b.mean()
     elbo = log_p_x_g_z - kl_div
     return elbo, log_p_x_g_z, kl_div, y_hat, logits
 

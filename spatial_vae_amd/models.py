@@ -111,7 +111,21 @@ class SpatialGenerator(nn.Module):
         latent_w = self.latent_linear.weight if self.latent_dim > 0 else None
         bil_w = self.bilinear.weight if hasattr(self, "bilinear") else None
         return ops.decoder(self._spec, B, coords, grid, theta, dx, z, self.coord_linear.weight, self.coord_linear.bias,
-                           latent_w, bil_w, out_lin.weight, out_lin.bias, hidden)
+                           latent_w, bil_w, out_lin.weight, out_lin.bias, hidden, sinks=getattr(self, "_grad_sinks", None))
+
+    def decoder_parameters(self):
+        """{sink name: parameter} in the naming ops.decoder uses for gradient sinks (see dp.FlatGrads)."""
+        hidden_lin, out_lin = self._linears()
+        named = {"coord_w": self.coord_linear.weight, "coord_b": self.coord_linear.bias, "out_w": out_lin.weight,
+                 "out_b": out_lin.bias}
+        if self.latent_dim > 0:
+            named["latent_w"] = self.latent_linear.weight
+        if hasattr(self, "bilinear"):
+            named["bilinear_w"] = self.bilinear.weight
+        for i, m in enumerate(hidden_lin):
+            named["hidden%d" % (2 * i)] = m.weight
+            named["hidden%d" % (2 * i + 1)] = m.bias
+        return named
 
     # -- the reference's entry point ----------------------------------------------------------
     def forward(self, x, z):

@@ -74,7 +74,7 @@ class _Decoder(torch.autograd.Function):
     """y, logits = decoder(coords | grid+theta+dx, z; parameters)   (svae_decoder_forward/backward)."""
 
     @staticmethod
-    def forward(ctx, spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden):
+    def forward(ctx, spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden):
         L = _lib.lib()
         ref = coords if coords is not None else grid
         _require_hip(ref, "coordinates")
@@ -109,6 +109,7 @@ class _Decoder(torch.autograd.Function):
                                               y.data_ptr(), logits.data_ptr(), _p(saved), ws.data_ptr(), ws.numel(),
                                               _stream(device)))
         ctx.spec, ctx.B, ctx.N = spec, B, N
+        ctx.sinks = sinks
         ctx.saved_buf = saved
         ctx.tensors = (coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits)
         ctx.mark_non_differentiable(logits)
@@ -127,17 +128,26 @@ class _Decoder(torch.autograd.Function):
                               bilinear_w if bil else None, out_w, out_b, hidden)
         pose = _lib.Pose()
         pose.coords, pose.grid, pose.theta, pose.dx = _p(coords), _p(grid), _p(theta), _p(dx)
-        ng = ctx.needs_input_grad  # (spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden)
+        # (spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden)
+        ng = ctx.needs_input_grad
+        sinks = ctx.sinks or {}
 
-        def new(t, want):
-            return torch.empty_like(t) if (t is not None and want) else None
+        def new(t, want, key=None):
+            """Gradient buffer: the caller's sink (a view of a flat gradient buffer the kernels write
+            into directly, see dp.FlatGrads) when one is registered for this parameter, else fresh."""
+            if t is None or not want:
+                return None
+            sk = sinks.get(key) if key is not None else None
+            if sk is not None and sk.shape == t.shape and sk.dtype == torch.float32 and sk.is_contiguous():
+                return sk
+            return torch.empty_like(t)
 
-        g_coords, g_theta, g_dx, g_z = new(coords, ng[2]), new(theta, ng[4]), new(dx, ng[5]), new(z, ng[6] and spec.latent_dim > 0)
-        g_cw, g_cb = new(coord_w, ng[7]), new(coord_b, ng[8])
-        g_lw = new(latent_w, ng[9] and spec.latent_dim > 0)
-        g_bw = new(bilinear_w, ng[10] and bil)
-        g_ow, g_ob = new(out_w, ng[11]), new(out_b, ng[12])
-        g_hidden = tuple(new(h, ng[13 + i]) for i, h in enumerate(hidden))
+        g_coords, g_theta, g_dx, g_z = new(coords, ng[3]), new(theta, ng[5]), new(dx, ng[6]), new(z, ng[7] and spec.latent_dim > 0)
+        g_cw, g_cb = new(coord_w, ng[8], "coord_w"), new(coord_b, ng[9], "coord_b")
+        g_lw = new(latent_w, ng[10] and spec.latent_dim > 0, "latent_w")
+        g_bw = new(bilinear_w, ng[11] and bil, "bilinear_w")
+        g_ow, g_ob = new(out_w, ng[12], "out_w"), new(out_b, ng[13], "out_b")
+        g_hidden = tuple(new(h, ng[14 + i], "hidden%d" % i) for i, h in enumerate(hidden))
         grads = _fill_params(_lib.Params(), g_cw, g_cb, g_lw, g_bw, g_ow, g_ob, g_hidden)
         pg = _lib.PoseGrads()
         pg.dcoords, pg.dtheta, pg.ddx = _p(g_coords), _p(g_theta), _p(g_dx)
@@ -149,13 +159,59 @@ class _Decoder(torch.autograd.Function):
                                                ctypes.byref(grads), _p(g_z), ctypes.byref(pg), ws.data_ptr(), ws.numel(),
                                                _stream(device)))
         ctx.saved_buf = None
-        return (None, None, g_coords, None, g_theta, g_dx, g_z, g_cw, g_cb, g_lw, g_bw, g_ow, g_ob) + g_hidden
+        return (None, None, None, g_coords, None, g_theta, g_dx, g_z, g_cw, g_cb, g_lw, g_bw, g_ow, g_ob) + g_hidden
 
 
-def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden):
-    """Returns (y, logits), each (B, N, n_out).  Exactly one of coords / grid is given."""
-    return _Decoder.apply(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b,
+def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, sinks=None):
+    """Returns (y, logits), each (B, N, n_out).  Exactly one of coords / grid is given.
+    sinks: optional {name: tensor} of preallocated parameter-gradient buffers (names coord_w, coord_b,
+    latent_w, bilinear_w, out_w, out_b, hidden0, hidden1, ...) the backward kernels write into."""
+    return _Decoder.apply(spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b,
                           *hidden)
+
+
+class _Latent(torch.autograd.Function):
+    """theta, dx, z_content, kl = latent_head(q_out, r)   (svae_latent_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, q_out, r, rotate, translate, mu_penalty, dx_scale, z_scale, theta_prior):
+        L = _lib.lib()
+        _require_hip(q_out, "encoder output")
+        q_out, r = _f32(q_out), _f32(r)
+        B, inf = r.shape
+        if q_out.shape != (B, 2 * inf):
+            raise RuntimeError("q_out must be (%d, %d), got %s" % (B, 2 * inf, tuple(q_out.shape)))
+        d = _lib.LatentDesc(B, inf, int(bool(rotate)), int(bool(translate)), int(bool(mu_penalty)), float(dx_scale),
+                            float(z_scale), float(theta_prior))
+        dev = q_out.device
+        zd = inf - (1 if rotate else 0) - (2 if translate else 0)
+        theta = torch.empty(B, dtype=torch.float32, device=dev) if rotate else None
+        dx = torch.empty(B, 2, dtype=torch.float32, device=dev) if translate else None
+        zc = torch.empty(B, zd, dtype=torch.float32, device=dev)
+        kl = torch.empty(B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.svae_latent_forward(ctypes.byref(d), q_out.data_ptr(), r.data_ptr(), _p(theta), _p(dx),
+                                             zc.data_ptr() if zd > 0 else None, kl.data_ptr(), _stream(dev)))
+        ctx.desc, ctx.q_out, ctx.r = d, q_out, r
+        return theta, dx, zc, kl
+
+    @staticmethod
+    def backward(ctx, g_theta, g_dx, g_zc, g_kl):
+        L = _lib.lib()
+        q_out, r = ctx.q_out, ctx.r
+        g_theta, g_dx, g_zc, g_kl = _f32(g_theta), _f32(g_dx), _f32(g_zc), _f32(g_kl)
+        if g_zc is not None and g_zc.numel() == 0:
+            g_zc = None
+        gq = torch.empty_like(q_out)
+        with torch.cuda.device(q_out.device):
+            _lib.check(L.svae_latent_backward(ctypes.byref(ctx.desc), q_out.data_ptr(), r.data_ptr(), _p(g_theta), _p(g_dx),
+                                              _p(g_zc), _p(g_kl), gq.data_ptr(), _stream(q_out.device)))
+        return gq, None, None, None, None, None, None, None
+
+
+def latent_head(q_out, r, rotate, translate, mu_penalty, dx_scale, z_scale, theta_prior):
+    """(theta | None, dx | None, z_content, kl_per_image) from the encoder output [z_mu | z_logstd] and the noise r."""
+    return _Latent.apply(q_out, r, rotate, translate, mu_penalty, dx_scale, z_scale, theta_prior)
 
 
 class _BceLoglik(torch.autograd.Function):
