@@ -290,9 +290,10 @@ void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first =
 template <int ACT>
 void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
     Scope prof(K_LAYER0_FWD, st);
-    const long total = g.noct * g.Hp * 2;
-    hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(total)), dim3(256), 0, st, pa, pl.posebuf, pl.tab, a0,
-                       row_geo(g), total);
+    const unsigned gy = (unsigned)(g.noct < 32768 ? g.noct : 32768);
+    const unsigned gz = (unsigned)((g.noct + gy - 1) / gy);
+    hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(g.Hp * 2), gy, gz), dim3(256), 0, st, pa, pl.posebuf,
+                       pl.tab, a0, row_geo(g), g.noct);
 }
 
 template <int C>

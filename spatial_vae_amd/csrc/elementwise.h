@@ -70,16 +70,15 @@ struct RowGeo {
 // output offset, so the 411 MB stream (BASELINE cfg 2) is written perfectly linearly.
 template <int ACT>
 __global__ void layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ posebuf, const float* __restrict__ tab,
-                                  float* __restrict__ a0, RowGeo g, long total) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int h = t & 1;
-    const long ok = t >> 1;
-    const int k = ok % g.Hp;
-    const long o = ok / g.Hp;
-    const long m0 = 8 * o + 4 * h;
-    const int b = m0 / g.Npad;
-    const int i0 = m0 % g.Npad;
+                                  float* __restrict__ a0, RowGeo g, long noct) {
+    // grid: x covers the Hp*2 (feature, half) pairs of one row octet, (y, z) the octets: no 64-bit divisions
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const long o = (long)blockIdx.z * gridDim.y + blockIdx.y;
+    if (t >= g.Hp * 2 || o >= noct) return;
+    const int h = t & 1, k = t >> 1;
+    const int oimg = g.Npad >> 3;
+    const int b = (int)(o / oimg);
+    const int i0 = ((int)(o - (long)b * oimg) << 3) + 4 * h;
     const float4 pb = posebuf[b];
     const float4* tp = reinterpret_cast<const float4*>(tab + ((long)b * g.Hp + k) * kSlots);
     const float4 t0 = tp[0], t1 = tp[1];
@@ -91,7 +90,7 @@ __global__ void layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ pose
         if (g.in_dim == 5) v += (x.x * x.x) * t0.z + (x.y * x.y) * t0.w + (x.x * x.y) * t1.x;
         out[e] = act_fwd<ACT>(v);
     }
-    *reinterpret_cast<float4*>(a0 + t * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<float4*>(a0 + (o * g.Hp * 2 + t) * 4) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 // ---------------------------------------------------------------- output layer, forward (A4)

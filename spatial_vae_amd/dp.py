@@ -24,10 +24,14 @@ def env_world():
 def init_process_group(device_is_gpu):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun sets them)."""
     rank, world, local = env_world()
+    # rehearsal on a 1-GPU box: SVAE_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the collective
+    share = os.environ.get("SVAE_SHARE_GPU") == "1"
+    if share:
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if device_is_gpu:
+        if device_is_gpu and not share:
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:

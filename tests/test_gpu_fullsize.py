@@ -1,0 +1,122 @@
+"""Parity at the BASELINE.json sizes (GPU): the HIP path against the CPU oracle on the same seeded
+inputs, plus size-independent properties (batch-shard additivity of the gradient = what data-parallel
+training relies on; linearity in the upstream gradient).  The oracle's fp32 numpy GEMMs take a few
+seconds at these sizes.  Tolerances: 1e-4 relative-to-max (north star), tighter where summation
+lengths allow."""
+import contextlib
+import io
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import cases as C
+from helpers import rel_err
+from oracle import elbo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# (name, script, n, B, z_dim, H, L, n_out, extra): BASELINE.json configs 2, 3, 4 (reduced batch: the
+# oracle needs B*N*H*4 bytes per activation plane on the host), 5
+FULL = [
+    ("cfg2_mnist_rt_B256", dict(script="mnist", n=28, m=28, B=256, z_dim=2, H=500, L=2, theta_prior=math.pi / 4)),
+    ("cfg3_5hdb_noise_B64", dict(script="particles", n=40, m=40, B=64, z_dim=2, H=500, L=2, n_out=2, theta_prior=math.pi)),
+    ("cfg4_galaxy_B2", dict(script="galaxy", n=128, m=128, B=2, z_dim=20, H=1024, L=3, n_out=3, theta_prior=math.pi)),
+    ("cfg5_ctf_B32", dict(script="particles", n=40, m=40, B=32, z_dim=8, H=500, L=2, ctf=True, theta_prior=math.pi)),
+]
+
+
+def _case(name, kw):
+    base = C._case(name, q_hidden=64, q_layers=1, seed=77, **kw)
+    return base
+
+
+def _run_gpu(case, inp):
+    import spatial_vae.models as models
+    from spatial_vae_amd import elbo as E
+    dev = torch.device("cuda:0")
+    with contextlib.redirect_stdout(io.StringIO()):
+        p_net = models.SpatialGenerator(case["z_dim"], case["H"], n_out=case["n_out"], num_layers=case["L"], activation=nn.Tanh)
+        n_in = case["n"] * case["m"] * (case["n_out"] if case["script"] == "galaxy" else 1)
+        q_net = models.InferenceNetwork(n_in, C.inf_dim(case), case["q_hidden"], num_layers=1, activation=nn.Tanh)
+    p_net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["p_state"].items()})
+    q_net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["q_state"].items()})
+    p_net.to(dev)
+    q_net.to(dev)
+    x = torch.from_numpy(inp["x_coord"]).to(dev)
+    y = torch.from_numpy(inp["y"]).to(dev)
+    r = torch.from_numpy(inp["r"]).to(dev)
+    kw = dict(rotate=True, translate=True, dx_scale=case["dx_scale"], theta_prior=case["theta_prior"], noise=r,
+              return_logits=True)
+    if case["script"] == "mnist":
+        elbo, log_p, kl, _, logits = E.eval_minibatch_mnist(x, y, p_net, q_net, **kw)
+    elif case["script"] == "galaxy":
+        elbo, log_p, kl, _, logits = E.eval_minibatch_galaxy(x, y, p_net, q_net, **kw)
+    else:
+        ctf = torch.from_numpy(inp["ctf"]).to(dev) if inp["ctf"] is not None else None
+        elbo, log_p, kl, logits = E.eval_minibatch_particles(x, y, None, ctf, p_net, q_net, **kw)
+    (-elbo).backward()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        q_out = q_net.layers(y.view(y.size(0), -1)).cpu().numpy()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in p_net.named_parameters()}
+    return elbo.item(), log_p.item(), kl.item(), logits.detach().cpu().numpy(), grads, q_out, (p_net, q_net, x, y, r)
+
+
+@pytest.mark.parametrize("name,kw", FULL, ids=[f[0] for f in FULL])
+def test_full_size_matches_oracle(name, kw):
+    case = _case(name, kw)
+    inp = C.build_inputs(case)
+    elbo, log_p, kl, logits, grads, q_out, _ = _run_gpu(case, inp)
+    ref = O.elbo_minibatch(case["script"], O.DecoderSpec.from_case(case), inp["p_state"], inp["x_coord"], inp["y"], q_out,
+                           inp["r"], rotate=True, translate=True, dx_scale=case["dx_scale"], theta_prior=case["theta_prior"],
+                           ctf=inp["ctf"])
+    assert abs(elbo - float(ref["elbo"])) <= 1e-4 * abs(float(ref["elbo"]))
+    assert abs(log_p - float(ref["log_p"])) <= 1e-4 * abs(float(ref["log_p"]))
+    assert rel_err(logits, ref["logits"]) < 1e-4
+    for k, g in grads.items():
+        assert rel_err(g, ref["gP"][k]) < 2e-4, (name, k, rel_err(g, ref["gP"][k]))
+
+
+def test_gradient_is_additive_over_batch_shards():
+    """Data-parallel contract at BASELINE cfg 2 size: weighting each half-batch's gradient by its share of
+    the images reproduces the full-batch gradient (what one all-reduce of the flat gradient computes)."""
+    from spatial_vae_amd import elbo as E
+    case = _case(*FULL[0])
+    inp = C.build_inputs(case)
+    _, _, _, _, full, _, (p_net, q_net, x, y, r) = _run_gpu(case, inp)
+    B = y.size(0)
+    acc = {k: np.zeros_like(v) for k, v in full.items()}
+    for lo, hi in ((0, 100), (100, B)):                       # ragged on purpose
+        p_net.zero_grad(set_to_none=True)
+        q_net.zero_grad(set_to_none=True)
+        elbo = E.eval_minibatch_mnist(x, y[lo:hi], p_net, q_net, rotate=True, translate=True, dx_scale=case["dx_scale"],
+                                      theta_prior=case["theta_prior"], noise=r[lo:hi])[0]
+        ((-elbo) * ((hi - lo) / B)).backward()
+        for k, p in p_net.named_parameters():
+            acc[k] += p.grad.detach().cpu().numpy()
+    for k in full:
+        assert rel_err(acc[k], full[k]) < 5e-5, k
+
+
+def test_decoder_backward_is_linear_in_upstream_gradient():
+    import spatial_vae.models as models
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = models.SpatialGenerator(2, 500, num_layers=2, activation=nn.Tanh).to(dev)
+    x = (torch.rand(8, 784, 2, device=dev) * 2 - 1).requires_grad_(True)
+    z = torch.randn(8, 2, device=dev)
+    g1, g2 = torch.randn(8, 784, 1, device=dev), torch.randn(8, 784, 1, device=dev)
+
+    def grads(up):
+        p.zero_grad(set_to_none=True)
+        x.grad = None
+        p(x, z).backward(up)
+        return [q.grad.clone() for q in p.parameters()] + [x.grad.clone()]
+
+    a, b, ab = grads(g1), grads(g2), grads(2.0 * g1 - 3.0 * g2)
+    for u, v, w in zip(a, b, ab):
+        assert rel_err((2.0 * u - 3.0 * v).cpu().numpy(), w.cpu().numpy()) < 2e-5
