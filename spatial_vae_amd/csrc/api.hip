@@ -113,8 +113,9 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.do_p = cw.take<float>((size_t)g.C * g.Mp);
     p.slab = cw.take<float>((size_t)p.wg_S * g.Hp * g.Hp);
     p.bslab = cw.take<float>((size_t)p.wg_S * 2 * g.Hp);
-    p.wpart = cw.take<float>((size_t)p.ob_chunks * 2 * g.C * g.Hp);
-    p.bpart = cw.take<float>((size_t)p.ob_chunks * 2 * g.C);
+    const size_t nparts = (size_t)(p.ob_chunks > p.wg_S ? p.ob_chunks : p.wg_S) * 2;  // out_bwd chunks or wgrad splits
+    p.wpart = cw.take<float>(nparts * g.C * g.Hp);
+    p.bpart = cw.take<float>(nparts * g.C);
     p.sgpart = cw.take<float>((size_t)g.B * p.l0_chunks_per_image * g.Hp * 2 * kSlots);
     p.sgimg = cw.take<float>((size_t)g.B * g.Hp * kSlots);
     p.dcoords = cw.take<float>((size_t)g.B * g.N * 2);
@@ -231,26 +232,39 @@ void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const Po
                            pl.wf[l], pl.wb[l], g.H, g.Hp);
 }
 
-template <int NT, bool DGRAD, bool RESID, bool FIRST>
+template <int NT, bool DGRAD, bool RESID, bool FIRST, bool LASTD>
 void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
+    // weight buffers, plus the W_o table (max channels x max width) behind them for LASTD
+    constexpr int kLds = DenseCfg<NT>::LDS_BYTES + (LASTD ? SVAE_MAX_OUT * 4096 * 4 : 0);
+    const int lds = DenseCfg<NT>::LDS_BYTES + (LASTD ? SVAE_MAX_OUT * a.Hp * 4 : 0);
     static bool attr_set = false;  // LDS beyond 64 KiB needs the opt-in attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID, FIRST>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, DenseCfg<NT>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID, FIRST, LASTD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLds < 160 * 1024 ? kLds : 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID, FIRST>), grid, dim3(256), DenseCfg<NT>::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID, FIRST, LASTD>), grid, dim3(256), lds, st, a);
 }
 
 template <int NT, bool DGRAD>
-void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false) {
-    if (DGRAD && first) {
-        if (a.resid) launch_dense_ntr<NT, true, true, true>(a, grid, st);
-        else launch_dense_ntr<NT, true, false, true>(a, grid, st);
-    } else {
-        if (a.resid) launch_dense_ntr<NT, DGRAD, true, false>(a, grid, st);
-        else launch_dense_ntr<NT, DGRAD, false, false>(a, grid, st);
+void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false, bool lastd = false) {
+    // The fused variants (FIRST epilogue / LASTD prologue) carry more live registers; at NT >= 8 hipcc starts to
+    // re-home the in-flight registers of the asm loads (tools/check_asm_loads.py), so those instantiations do
+    // not exist: dense_nt_first() caps the column tiles at 4 for them.
+    if constexpr (DGRAD && NT <= 4) {
+      if (first || lastd) {
+        if (lastd) {  // never with a residual (checked by the caller)
+            if (first) launch_dense_ntr<NT, true, false, true, true>(a, grid, st);
+            else launch_dense_ntr<NT, true, false, false, true>(a, grid, st);
+        } else {
+            if (a.resid) launch_dense_ntr<NT, true, true, true, false>(a, grid, st);
+            else launch_dense_ntr<NT, true, false, true, false>(a, grid, st);
+        }
+        return;
+      }
     }
+    if (a.resid) launch_dense_ntr<NT, DGRAD, true, false, false>(a, grid, st);
+    else launch_dense_ntr<NT, DGRAD, false, false, false>(a, grid, st);
 }
 
 // column tiles accumulated per pass: the widest that divides the layer, unless SVAE_DENSE_NT caps it
@@ -265,25 +279,46 @@ int dense_nt_for(int ntile) {
     return nt;
 }
 
-// the fused first-layer epilogue keeps 64 extra values per lane: it runs with half the column tiles
+// the fused variants (first-layer epilogue, last-layer prologue) keep more values live: at most 4 column tiles
 int dense_nt_first(int ntile) {
     int nt = dense_nt_for(ntile);
-    static const int cap = [] { const char* e = getenv("SVAE_FIRST_NT"); return e ? atoi(e) : 4; }();
-    while (nt > cap && nt > 1) nt >>= 1;
+    while (nt > 4) nt >>= 1;
     return nt;
 }
 
 template <bool DGRAD>
-void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false) {
+void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
-    const int nt = first ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
+    const int nt = (first || lastd) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
     switch (nt) {
-        case 16: launch_dense_nt<16, DGRAD>(a, grid, st, first); break;
-        case 8: launch_dense_nt<8, DGRAD>(a, grid, st, first); break;
-        case 4: launch_dense_nt<4, DGRAD>(a, grid, st, first); break;
-        case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first); break;
-        default: launch_dense_nt<1, DGRAD>(a, grid, st, first); break;
+        case 16: launch_dense_nt<16, DGRAD>(a, grid, st, first, lastd); break;
+        case 8: launch_dense_nt<8, DGRAD>(a, grid, st, first, lastd); break;
+        case 4: launch_dense_nt<4, DGRAD>(a, grid, st, first, lastd); break;
+        case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first, lastd); break;
+        default: launch_dense_nt<1, DGRAD>(a, grid, st, first, lastd); break;
+    }
+}
+
+template <int CL>
+void launch_wgrad_c(const WgradArgs& w, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;  // 144 KiB of LDS (4 waves x 4 ring slots x 9 KiB) needs the opt-in
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<CL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kWgradLdsBytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<CL>), grid, dim3(256), kWgradLdsBytes, st, w);
+}
+
+void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, hipStream_t st) {
+    Scope prof(K_WGRAD, st);
+    switch (cl) {
+        case 1: launch_wgrad_c<1>(w, grid, st); break;
+        case 2: launch_wgrad_c<2>(w, grid, st); break;
+        case 3: launch_wgrad_c<3>(w, grid, st); break;
+        case 4: launch_wgrad_c<4>(w, grid, st); break;
+        default: launch_wgrad_c<0>(w, grid, st); break;
     }
 }
 
@@ -375,6 +410,7 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
         a.resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
         a.pose = pa; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr; a.dfpart = nullptr;
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
+        a.do_p = nullptr; a.out_w = nullptr; a.C = g.C;
         launch_dense<false>(g, a, st);
     }
     switch (g.C) {
@@ -413,16 +449,21 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                            pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
     }
 
-    // output layer: dh_{L-1}, dW_o, db_o
+    // Output layer.  With at least one hidden layer and no residual, dh_{L-1} is never materialised: both
+    // GEMMs of the last hidden layer form it from a_{L-1} on the fly (LASTW / LASTD) and the weight-gradient
+    // kernel also produces dW_o, db_o.  Otherwise: one streaming pass (out_bwd_kernel).
     int cur = 0;
-    const float* alast = pl.act[g.L - 1];
-    switch (g.act) {
-        case SVAE_ACT_TANH: launch_out_bwd_a<SVAE_ACT_TANH>(g, pl, alast, p, pl.dh[cur], st); break;
-        case SVAE_ACT_LEAKYRELU: launch_out_bwd_a<SVAE_ACT_LEAKYRELU>(g, pl, alast, p, pl.dh[cur], st); break;
-        case SVAE_ACT_RELU: launch_out_bwd_a<SVAE_ACT_RELU>(g, pl, alast, p, pl.dh[cur], st); break;
-        default: launch_out_bwd_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, pl.dh[cur], st); break;
-    }
-    {
+    const char* fuse_env = getenv("SVAE_FUSE_OUT");  // opt-in: slower on fp32 MFMA (see wgrad_kernel), saves a 419 MB plane
+    const bool fused_out = fuse_env && fuse_env[0] == '1' && g.L >= 2 && !resid &&
+                           (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]);
+    if (!fused_out) {
+        const float* alast = pl.act[g.L - 1];
+        switch (g.act) {
+            case SVAE_ACT_TANH: launch_out_bwd_a<SVAE_ACT_TANH>(g, pl, alast, p, pl.dh[cur], st); break;
+            case SVAE_ACT_LEAKYRELU: launch_out_bwd_a<SVAE_ACT_LEAKYRELU>(g, pl, alast, p, pl.dh[cur], st); break;
+            case SVAE_ACT_RELU: launch_out_bwd_a<SVAE_ACT_RELU>(g, pl, alast, p, pl.dh[cur], st); break;
+            default: launch_out_bwd_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, pl.dh[cur], st); break;
+        }
         Scope prof(K_SMALL_BWD, st);
         hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
                            grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2);
@@ -431,31 +472,28 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     // hidden layers, last to first
     bool fused_first = false;
     for (int l = g.L - 1; l >= 1; --l) {
+        const bool last = fused_out && l == g.L - 1;
         if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1]) {
             WgradArgs w;
-            w.dh = pl.dh[cur];
+            w.dh = last ? pl.act[l] : pl.dh[cur];
             w.aprev = pl.act[l - 1];
             w.slab = pl.slab;
             w.bslab = pl.bslab;
             w.noct = g.noct;
             w.Hp = g.Hp;
             w.nblk1 = pl.wg_nblk1;
-            {
-                Scope prof(K_WGRAD, st);
-                static bool attr_set = false;  // 128 KiB of LDS (4 waves x 4 slots x 8 KiB) needs the opt-in
-                if (!attr_set) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLdsBytes);
-                    attr_set = true;
-                }
-                hipLaunchKernelGGL(wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), kWgradLdsBytes, st, w);
-            }
+            w.do_p = pl.do_p; w.out_w = p->out_w; w.wpart = pl.wpart; w.bpart = pl.bpart;
+            w.Mp = g.Mp; w.H = g.H; w.act = g.act;
+            launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
             Scope prof(K_WGRAD_REDUCE, st);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
                                grads->hidden_w[l - 1], grads->hidden_b[l - 1], g.H, g.Hp, pl.wg_S);
+            if (last)
+                hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
+                                   grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.wg_S * 2);
         }
         DenseArgs a;
-        a.in = pl.dh[cur];
+        a.in = last ? pl.act[l] : pl.dh[cur];
         a.wp = pl.wb[l - 1];
         a.out = pl.dh[cur ^ 1];
         a.bias = nullptr;
@@ -467,8 +505,9 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         a.resid = resid;
         a.pose = pa; a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile; a.dfpart = pl.dfpart;
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
+        a.do_p = pl.do_p; a.out_w = p->out_w; a.C = g.C;
         fused_first = (l == 1) && g.in_dim == 2;
-        launch_dense<true>(g, a, st, fused_first);
+        launch_dense<true>(g, a, st, fused_first, last);
         cur ^= 1;
     }
 

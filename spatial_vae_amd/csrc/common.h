@@ -95,6 +95,27 @@ __device__ __forceinline__ float act_grad(float a) {
     return a * (1.0f - a);
 }
 
+// act' through the activation output a with the activation chosen at run time, WITHOUT branches (it is used per
+// element inside MFMA loops): smooth activations are c0 + a*(c1 + c2*a) (tanh: 1 - a^2, sigmoid: a - a^2), the
+// rectifiers a > 0 ? 1 : slope; the coefficients are wave-uniform.
+struct ActCoef {
+    float c0, c1, c2, slope, rect;  // rect = 1 for the rectifiers, 0 otherwise
+};
+__device__ __forceinline__ ActCoef act_coef(int act) {
+    ActCoef k;
+    k.c0 = act == SVAE_ACT_TANH ? 1.0f : 0.0f;
+    k.c1 = act == SVAE_ACT_SIGMOID ? 1.0f : 0.0f;
+    k.c2 = (act == SVAE_ACT_TANH || act == SVAE_ACT_SIGMOID) ? -1.0f : 0.0f;
+    k.slope = act == SVAE_ACT_LEAKYRELU ? 0.01f : 0.0f;
+    k.rect = (act == SVAE_ACT_LEAKYRELU || act == SVAE_ACT_RELU) ? 1.0f : 0.0f;
+    return k;
+}
+__device__ __forceinline__ float act_grad_rt(const ActCoef& k, float a) {
+    const float poly = k.c0 + a * (k.c1 + k.c2 * a);
+    const float rl = a > 0.0f ? 1.0f : k.slope;
+    return poly + k.rect * (rl - poly);
+}
+
 // coordinates of pixel i of image b (i < N), from explicit coords or grid + pose
 __device__ __forceinline__ float2 pixel_coord(const PoseArgs& p, int b, int i, int N, float c, float s, float dx0,
                                               float dx1) {

@@ -50,6 +50,11 @@ struct DenseArgs {
     float* dfpart;          // [Hp/NB][Mp][2]
     long Mp;
     int N, Timg;
+    // LASTD (data gradient out of the LAST hidden layer, no residual): `in` is a_{L-1} itself and the row
+    // operand dh_{L-1}[m][n] = (sum_c do[m][c] W_o[c][n]) * act'(a_{L-1}[m][n]) is formed in registers
+    const float* do_p;   // [C][Mp] d(loss)/d(logits), zero on pad rows
+    const float* out_w;  // (C, H)
+    int C;
 };
 
 template <int ACT, bool DGRAD>
@@ -141,9 +146,10 @@ struct DenseCfg {
     static constexpr int NINSTR = G * NT;              // 1 KiB global_load_lds wave-instructions per chunk
 };
 
-template <int NT, bool DGRAD, bool RESID, bool FIRST = false>
+template <int NT, bool DGRAD, bool RESID, bool FIRST = false, bool LASTD = false>
 __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArgs a) {
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
+    static_assert(!LASTD || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using Cfg = DenseCfg<NT>;
     constexpr int NB = Cfg::NB, G = Cfg::G, CHUNK = Cfg::CHUNK, NINSTR = Cfg::NINSTR;
@@ -211,6 +217,36 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
         //     at the end of chunk c         : vmcnt(P)  -> A(c+1) has landed, DMA(c+2) may be in flight
         constexpr int P = NINSTR / 4;
         static_assert(G == 4, "load_a_chunk moves 4 octets");
+        // LASTD: W_o (zero-padded to Hp) into LDS behind the weight buffers, this lane's row of d(logits) into
+        // registers.  These compiler-visible loads come before any asm memory operation of the kernel.
+        float* wo_lds = smem + 2 * CHUNK;
+        const ActCoef acoef = act_coef(a.act);
+        float dlog[SVAE_MAX_OUT] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (LASTD) {
+            for (int i = threadIdx.x; i < SVAE_MAX_OUT * Hp; i += 256) {  // unused channels are zero rows: no branches later
+                const int c = i / Hp, n = i - c * Hp;
+                wo_lds[i] = (c < a.C && n < a.H) ? a.out_w[c * a.H + n] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < SVAE_MAX_OUT; ++c) {
+                const float v = a.do_p[(long)(c < a.C ? c : 0) * a.Mp + tl * 32 + nl];
+                dlog[c] = c < a.C ? v : 0.0f;
+            }
+        }
+        // dh = (sum_c dlog_c * W_o[c][k]) * act'(a) for the 16 values of one chunk (k = 8*(c*G+gl) + 4h + e)
+        auto to_dh = [&](int c, float (&v)[G][4]) {
+#pragma unroll
+            for (int gl = 0; gl < G; ++gl) {
+                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int cc = 0; cc < SVAE_MAX_OUT; ++cc) {
+                    const float4 w = *reinterpret_cast<const float4*>(wo_lds + cc * Hp + (c * G + gl) * 8 + 4 * h);
+                    s[0] += dlog[cc] * w.x; s[1] += dlog[cc] * w.y; s[2] += dlog[cc] * w.z; s[3] += dlog[cc] * w.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[gl][e] = s[e] * act_grad_rt(acoef, v[gl][e]);
+            }
+        };
         stage(0, 0);
         stage(nchunk > 1 ? 1 : 0, 1);
         float ac[G][4], an[G][4];
@@ -221,11 +257,12 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
             for (int e = 0; e < 4; ++e) an[gl][e] = 0.0f;
         load_a_chunk(arow, an);
         wait_vm_chunk<0>(an);
-        __syncthreads();  // chunks 0 and 1 have landed in LDS
+        __syncthreads();  // chunks 0 and 1 (and the W_o table) have landed in LDS
 #pragma unroll
         for (int gl = 0; gl < G; ++gl)
 #pragma unroll
             for (int e = 0; e < 4; ++e) ac[gl][e] = an[gl][e];
+        if (LASTD) to_dh(0, ac);
         read_b(0, b0);
         const int spare = nchunk & 1;  // buffer that held chunk nchunk-2: the sink of redundant re-stages
         for (int c = 0; c < nchunk; ++c) {
@@ -238,7 +275,8 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
                     // the next octet opens chunk c+1: its DMA must have landed in every wave's view, and
                     // every wave must hold its last fragments of chunk c before that buffer is reused
                     if (!(SVAE_ABLATE & 64)) {
-                        wait_vm_chunk<16>(ac);
+                        if (LASTD) wait_vm_chunk<0>(an);  // A(c+1) too (issued three octets ago): its transform overlaps this octet
+                        else wait_vm_chunk<16>(ac);
                         __syncthreads();
                     }
                     const bool more = c + 2 < nchunk;
@@ -248,13 +286,19 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
                 if (!(SVAE_ABLATE & 4)) {
                     if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(SVAE_ABLATE & 16) || (gl & 1)) {
-                    if (gl & 1) mfma_octet(ac[gl], b1); else mfma_octet(ac[gl], b0);
+                if (LASTD && gl == G - 1) {
+                    // no pinning here: the scheduler may weave the transform of the next chunk into this octet's MFMAs
+                    to_dh(c + 1 < nchunk ? c + 1 : nchunk - 1, an);
+                    mfma_octet(ac[gl], b1);
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(SVAE_ABLATE & 16) || (gl & 1)) {
+                        if (gl & 1) mfma_octet(ac[gl], b1); else mfma_octet(ac[gl], b0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-            wait_vm_chunk<P>(an);
+            if (!LASTD) wait_vm_chunk<P>(an);
 #pragma unroll
             for (int gl = 0; gl < G; ++gl)
 #pragma unroll
@@ -412,6 +456,13 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
 // slab[split] and are summed in fixed order by wgrad_reduce_kernel (deterministic, no atomics).
 // ------------------------------------------------------------------------------------------
 struct WgradArgs {
+    // LASTW (weight gradient of the LAST hidden layer): `dh` is a_{L-1} and dh is formed from it in registers
+    const float* do_p;   // [C][Mp]
+    const float* out_w;  // (C, H)
+    float* wpart;        // [S][2][C][Hp] partial dW_o (layout of out_bwd_kernel's wpart)
+    float* bpart;        // [S][2][C] partial db_o
+    long Mp;
+    int H, act;
     const float* dh;     // octet-major (Mp x Hp): dh_l
     const float* aprev;  // octet-major (Mp x Hp): a_{l-1}
     float* slab;         // [S][Hp][Hp]
@@ -421,8 +472,16 @@ struct WgradArgs {
     int nblk1;           // blocks per side = ceil(ntile / 8)
 };
 
-constexpr int kWgradLdsBytes = 4 * 4 * 8 * 1024;  // 4 waves x 4 ring slots x 8 KiB
+constexpr int kWgradLdsBytes = 4 * 4 * 9 * 1024;  // 4 waves x 4 ring slots x (8 operand pieces + 1 d(logits) piece) KiB
 
+// Measured (r01): on gfx950 the fp32 MFMA does not overlap with VALU work -- weaving the transform's VALU
+// instructions between the MFMAs (sched_group_barrier 1:3) made this kernel SLOWER (1.03 vs 0.96 ms; 0.82 ms
+// without the transform).  A per-element transform inside an fp32 GEMM loop costs MFMA-pipe time 1:1, so the
+// fused form below is opt-in (SVAE_FUSE_OUT=1); the default keeps out_bwd_kernel's streaming pass.
+// CL = 0: dh comes from HBM.  CL = C (1..4): LASTW, dh_{L-1} = (sum_c do_c W_o[c]) * act'(a_{L-1}) formed from the
+// a_{L-1} fragments, with the rows of d(logits) arriving as a 9th DMA piece per octet; the waves of output
+// column-block 0 also accumulate dW_o[c][n] = sum_m do[m][c] a_{L-1}[m][n] and db_o.
+template <int CL>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -465,7 +524,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     // The loop is branch-free: DMA and fragment reads past the end are clamped re-loads that are never
     // multiplied.
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int kSlotFloats = 8 * 256;  // 8 KiB
+    constexpr int kSlotFloats = 9 * 256;  // 8 operand pieces + 1 piece for the d(logits) rows (used when CL > 0)
+    constexpr int kPieces = CL > 0 ? 9 : 8;
     float* ring = smem + wave * (4 * kSlotFloats);
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
     const long ostride = (long)Hp * 8;
@@ -477,13 +537,59 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         for (int t = 0; t < 4; ++t) glds16(pa[t] + off, slot + t * 1024u);
 #pragma unroll
         for (int t = 0; t < 4; ++t) glds16(pb[t] + off, slot + (4 + t) * 1024u);
+        if (CL > 0) {
+            // lane (2c + hh) fetches do_p[c][8*oc + 4*hh .. +3]; the other lanes re-fetch lane 0's 16 bytes
+            const int c = (lane >> 1) < CL ? (lane >> 1) : 0, hh = (lane >> 1) < CL ? (lane & 1) : 0;
+            glds16(a.do_p + (long)c * a.Mp + oc * 8 + 4 * hh, slot + 8 * 1024u);
+        }
     };
+    // LASTW state: W_o for this lane's four dh columns, partial dW_o / db_o
+    const ActCoef acoef = act_coef(a.act);
+    float wo[CL > 0 ? CL : 1][4], pw[CL > 0 ? CL : 1][4], pbias[CL > 0 ? CL : 1];
+    const bool own_out = (CL > 0) && bj == 0 && (wave & 1) == 0;  // one wave per dh column tile
+    if (CL > 0) {
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+            pbias[c] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = (ibase + t) * 32 + nl;
+                wo[c][t] = (ibase + t < ntile && n < a.H) ? a.out_w[c * a.H + n] : 0.0f;
+                pw[c][t] = 0.0f;
+            }
+        }
+    }
     auto frag = [&](long o, float4 (&xa)[4], float4 (&xb)[4]) {
         const float* sl = ring + ((o - o0) & 3) * kSlotFloats + lane * 4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             xa[t] = *reinterpret_cast<const float4*>(sl + t * 256);
             xb[t] = *reinterpret_cast<const float4*>(sl + (4 + t) * 256);
+        }
+        if (CL > 0) {
+            const float* dl = ring + ((o - o0) & 3) * kSlotFloats + 8 * 256 + h * 4;
+            float4 d[CL > 0 ? CL : 1];
+#pragma unroll
+            for (int c = 0; c < CL; ++c) d[c] = *reinterpret_cast<const float4*>(dl + c * 8);
+            // dW_o / db_o partials; a clamped re-load (o >= o1) must not be accumulated twice: weight 0
+            const float wgt = (own_out && o < o1) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                pbias[c] += wgt * ((d[c].x + d[c].y) + (d[c].z + d[c].w));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    pw[c][t] += wgt * ((d[c].x * xa[t].x + d[c].y * xa[t].y) + (d[c].z * xa[t].z + d[c].w * xa[t].w));
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < CL; ++c) {
+                    s4.x += d[c].x * wo[c][t]; s4.y += d[c].y * wo[c][t]; s4.z += d[c].z * wo[c][t]; s4.w += d[c].w * wo[c][t];
+                }
+                xa[t] = make_float4(s4.x * act_grad_rt(acoef, xa[t].x), s4.y * act_grad_rt(acoef, xa[t].y),
+                                    s4.z * act_grad_rt(acoef, xa[t].z), s4.w * act_grad_rt(acoef, xa[t].w));
+            }
         }
     };
     auto mul = [&](const float4 (&xa)[4], const float4 (&xb)[4]) {
@@ -511,15 +617,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         dma(o0);
         dma(o0 + 1);
         dma(o0 + 2);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (CL > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         frag(o0, ca, cb);
         for (long o = o0; o < o1; ++o) {
             dma(o + 3);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // DMA(o+1) has landed
+            if (CL > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // DMA(o+1) has landed (9 pieces per octet)
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             frag(o + 1, na, nb);
-            __builtin_amdgcn_sched_barrier(0);
+            if (CL == 0) __builtin_amdgcn_sched_barrier(0);
             mul(ca, cb);
-            __builtin_amdgcn_sched_barrier(0);
+            if (CL == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 ca[t] = na[t];
@@ -542,6 +650,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
                 const int n = (ibase + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 slab[(long)n * Hp + k] = acc[i][j][r];
             }
+        }
+    }
+    if (own_out) {
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ibase + i < ntile) a.wpart[(((long)blockIdx.y * 2 + h) * CL + c) * Hp + (ibase + i) * 32 + nl] = pw[c][i];
+            if (bi == 0 && wave == 0 && nl == 0) a.bpart[((long)blockIdx.y * 2 + h) * CL + c] = pbias[c];
         }
     }
     if (bj == 0 && (wave & 1) == 0) {

@@ -98,3 +98,12 @@ def test_library_is_the_hip_one():
     from spatial_vae_amd import _lib
     L = _lib.lib()
     assert isinstance(L, ctypes.CDLL) and L.svae_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", ["mnist_rt", "mnist_L3", "mnist_leaky", "mnist_sigmoid_act", "galaxy_rgb", "particles_fit_noise",
+                                  "mnist_wide", "mnist_h500"])
+def test_fused_output_layer_backward_option(name, monkeypatch):
+    """SVAE_FUSE_OUT=1 forms dh_{L-1} inside the two GEMMs of the last hidden layer instead of the streaming
+    out_bwd pass (off by default: slower on fp32 MFMA); it must give the same gradients."""
+    monkeypatch.setenv("SVAE_FUSE_OUT", "1")
+    test_eval_minibatch_matches_reference(name)
