@@ -117,6 +117,17 @@ __device__ __forceinline__ void load_a_chunk(const float* p, float (&v)[4][4]) {
         : "v"(p)
         : "memory");
 }
+// one dword of the row operand at an immediate byte offset, into the register the variable lives in
+template <int OFF>
+__device__ __forceinline__ void load_a1(const float* p, float& v) {
+    asm volatile("global_load_dword %0, %1, off offset:%2" : "+v"(v) : "v"(p), "i"(OFF) : "memory");
+}
+// wait until at most N vector-memory operations are outstanding, tied to ONE register
+template <int N>
+__device__ __forceinline__ void wait_vm1(float& v) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "i"(N) : "memory");
+}
+
 // wait until at most N vector-memory operations of this wave are outstanding; the chunk registers are
 // passed through so that no use of them can be scheduled above the wait
 template <int N>
@@ -197,33 +208,28 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
 #pragma unroll
             for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(base + t * 256);
         };
-        auto mfma_octet = [&](const float (&av)[4], const float4 (&bc)[NT]) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bc[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bc[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bc[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bc[t].w, acc[t], 0, 0, 0);
-        };
-
-        // Main loop.  No branches (indices past the end are clamped: a harmless re-read / re-stage of
-        // valid data) and no compiler-visible vector-memory operation, so the only vmcnt waits are the
-        // two below.  Per wave the VMEM queue, oldest first, cycles through
-        //     ... DMA(c+1)[P] |top of chunk c| A(c+1)[16] |barrier of chunk c| DMA(c+2)[P] |end of chunk c| ...
-        // (P = NINSTR/4 DMA pieces per wave), hence
-        //     before the barrier of chunk c : vmcnt(16) -> DMA(c+1) has landed, A(c+1) may be in flight
-        //     at the end of chunk c         : vmcnt(P)  -> A(c+1) has landed, DMA(c+2) may be in flight
-        constexpr int P = NINSTR / 4;
-        static_assert(G == 4, "load_a_chunk moves 4 octets");
-        // LASTD: W_o (zero-padded to Hp) into LDS behind the weight buffers, this lane's row of d(logits) into
-        // registers.  These compiler-visible loads come before any asm memory operation of the kernel.
+        // Main loop.  No branches (indices past the end are clamped: a harmless re-read / re-stage of valid
+        // data) and no compiler-visible vector-memory operation.  The memory instructions are SPREAD: after
+        // every group of NT MFMAs (one k-step over the column tiles) the wave re-issues the single A-operand
+        // dword that this same group will need one chunk later, and -- in the chunk's last octet, behind the
+        // barrier -- its share of the next-but-one chunk's DMA pieces.  (Clumps of 16 loads / P DMA pieces left
+        // the MFMA pipe idle for hundreds of cycles per chunk.)
+        // Queue proof, per wave: a slot is [wait][NT MFMAs][A load][DMA pieces, last octet only].  Between the
+        // issue of an A dword and its use exactly one chunk (16 slots) later lie 15 A loads and P DMA pieces,
+        // for every slot, so ONE constant serves them all: s_waitcnt vmcnt(15 + P); in the first chunk fewer
+        // operations are outstanding and its operand was drained in the prologue.  Before the barrier in
+        // chunk c, the last DMA piece of chunk c+1 (issued at the end of chunk c-1) has the 12 A loads of
+        // slots 0..11 behind it: vmcnt(12).
+        constexpr int P = NINSTR / 4;       // DMA pieces per wave and chunk
+        constexpr int PE = (P + 3) / 4;     // ... per k-step of the last octet
+        static_assert(G == 4, "load_a_chunk / the slot offsets assume 4 octets per chunk");
+        // LASTD: W_o (zero rows for unused channels, zero-padded to Hp) into LDS behind the weight buffers, this
+        // lane's row of d(logits) into registers.  These compiler-visible loads precede every asm memory op.
         float* wo_lds = smem + 2 * CHUNK;
         const ActCoef acoef = act_coef(a.act);
         float dlog[SVAE_MAX_OUT] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (LASTD) {
-            for (int i = threadIdx.x; i < SVAE_MAX_OUT * Hp; i += 256) {  // unused channels are zero rows: no branches later
+            for (int i = threadIdx.x; i < SVAE_MAX_OUT * Hp; i += 256) {
                 const int c = i / Hp, n = i - c * Hp;
                 wo_lds[i] = (c < a.C && n < a.H) ? a.out_w[c * a.H + n] : 0.0f;
             }
@@ -233,78 +239,99 @@ __global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArg
                 dlog[c] = c < a.C ? v : 0.0f;
             }
         }
-        // dh = (sum_c dlog_c * W_o[c][k]) * act'(a) for the 16 values of one chunk (k = 8*(c*G+gl) + 4h + e)
-        auto to_dh = [&](int c, float (&v)[G][4]) {
-#pragma unroll
-            for (int gl = 0; gl < G; ++gl) {
-                float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int cc = 0; cc < SVAE_MAX_OUT; ++cc) {
-                    const float4 w = *reinterpret_cast<const float4*>(wo_lds + cc * Hp + (c * G + gl) * 8 + 4 * h);
-                    s[0] += dlog[cc] * w.x; s[1] += dlog[cc] * w.y; s[2] += dlog[cc] * w.z; s[3] += dlog[cc] * w.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[gl][e] = s[e] * act_grad_rt(acoef, v[gl][e]);
-            }
+        auto stage_piece = [&](int c, int buf, int j) {
+            const int idx = wave + 4 * j;
+            const int gl = idx / NT, tt = idx % NT;
+            const float* src = a.wp + ((long)(c * G + gl) * ntile + nb * NT + tt) * 256 + lane * 4;
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK + idx * 256) * 4u));
         };
         stage(0, 0);
         stage(nchunk > 1 ? 1 : 0, 1);
-        float ac[G][4], an[G][4];
+        float av[G][4];
         float4 b0[NT], b1[NT];
 #pragma unroll
         for (int gl = 0; gl < G; ++gl)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) an[gl][e] = 0.0f;
-        load_a_chunk(arow, an);
-        wait_vm_chunk<0>(an);
+            for (int e = 0; e < 4; ++e) av[gl][e] = 0.0f;
+        load_a_chunk(arow, av);
+        wait_vm_chunk<0>(av);
         __syncthreads();  // chunks 0 and 1 (and the W_o table) have landed in LDS
-#pragma unroll
-        for (int gl = 0; gl < G; ++gl)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ac[gl][e] = an[gl][e];
-        if (LASTD) to_dh(0, ac);
         read_b(0, b0);
         const int spare = nchunk & 1;  // buffer that held chunk nchunk-2: the sink of redundant re-stages
         for (int c = 0; c < nchunk; ++c) {
-            // A(c+1): issued here, awaited at the bottom of this same iteration (a whole chunk later)
-            if (!(SVAE_ABLATE & 8)) load_a_chunk(arow + (long)(c + 1 < nchunk ? c + 1 : nchunk - 1) * (G * 64), an);
+            const float* anext = arow + (long)(c + 1 < nchunk ? c + 1 : nchunk - 1) * (G * 64);
+            const bool more = c + 2 < nchunk;
+            const int cstage = more ? c + 2 : nchunk - 1, bstage = more ? (c & 1) : spare;
 #pragma unroll
             for (int gl = 0; gl < G; ++gl) {
                 const int o = c * G + gl;
                 if (gl == G - 1 && !(SVAE_ABLATE & 2)) {
                     // the next octet opens chunk c+1: its DMA must have landed in every wave's view, and
                     // every wave must hold its last fragments of chunk c before that buffer is reused
-                    if (!(SVAE_ABLATE & 64)) {
-                        if (LASTD) wait_vm_chunk<0>(an);  // A(c+1) too (issued three octets ago): its transform overlaps this octet
-                        else wait_vm_chunk<16>(ac);
-                        __syncthreads();
-                    }
-                    const bool more = c + 2 < nchunk;
-                    stage(more ? c + 2 : nchunk - 1, more ? (c & 1) : spare);
+                    wait_vm1<12>(av[gl][0]);
+                    __syncthreads();
                 }
                 const int onext = (o + 1 < noct) ? o + 1 : noct - 1;
                 if (!(SVAE_ABLATE & 4)) {
                     if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
                 }
-                if (LASTD && gl == G - 1) {
-                    // no pinning here: the scheduler may weave the transform of the next chunk into this octet's MFMAs
-                    to_dh(c + 1 < nchunk ? c + 1 : nchunk - 1, an);
-                    mfma_octet(ac[gl], b1);
-                } else {
+                float sdo[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (LASTD) {  // sum_c dlog_c * W_o[c][k] for this octet's four k-steps (k = 8o + 4h + e)
+                    sdo[0] = sdo[1] = sdo[2] = sdo[3] = 0.0f;
+#pragma unroll
+                    for (int cc = 0; cc < SVAE_MAX_OUT; ++cc) {
+                        const float4 w = *reinterpret_cast<const float4*>(wo_lds + cc * Hp + o * 8 + 4 * h);
+                        sdo[0] += dlog[cc] * w.x; sdo[1] += dlog[cc] * w.y; sdo[2] += dlog[cc] * w.z; sdo[3] += dlog[cc] * w.w;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wait_vm1<15 + P>(av[gl][e]);
+                    const float x = LASTD ? sdo[e] * act_grad_rt(acoef, av[gl][e]) : av[gl][e];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float4 bb = (gl & 1) ? b1[t] : b0[t];
+                        const float bv = e == 0 ? bb.x : e == 1 ? bb.y : e == 2 ? bb.z : bb.w;
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bv, acc[t], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!(SVAE_ABLATE & 16) || (gl & 1)) {
-                        if (gl & 1) mfma_octet(ac[gl], b1); else mfma_octet(ac[gl], b0);
+                    // re-issue this register's load for the next chunk (byte offset 256*gl + 32*e)
+                    if (!(SVAE_ABLATE & 8)) {
+                        if (gl == 0 && e == 0) load_a1<0>(anext, av[0][0]);
+                        if (gl == 0 && e == 1) load_a1<32>(anext, av[0][1]);
+                        if (gl == 0 && e == 2) load_a1<64>(anext, av[0][2]);
+                        if (gl == 0 && e == 3) load_a1<96>(anext, av[0][3]);
+                        if (gl == 1 && e == 0) load_a1<256>(anext, av[1][0]);
+                        if (gl == 1 && e == 1) load_a1<288>(anext, av[1][1]);
+                        if (gl == 1 && e == 2) load_a1<320>(anext, av[1][2]);
+                        if (gl == 1 && e == 3) load_a1<352>(anext, av[1][3]);
+                        if (gl == 2 && e == 0) load_a1<512>(anext, av[2][0]);
+                        if (gl == 2 && e == 1) load_a1<544>(anext, av[2][1]);
+                        if (gl == 2 && e == 2) load_a1<576>(anext, av[2][2]);
+                        if (gl == 2 && e == 3) load_a1<608>(anext, av[2][3]);
+                        if (gl == 3 && e == 0) load_a1<768>(anext, av[3][0]);
+                        if (gl == 3 && e == 1) load_a1<800>(anext, av[3][1]);
+                        if (gl == 3 && e == 2) load_a1<832>(anext, av[3][2]);
+                        if (gl == 3 && e == 3) load_a1<864>(anext, av[3][3]);
+                    }
+                    if (gl == G - 1 && !(SVAE_ABLATE & 2)) {  // this wave's DMA pieces of chunk c+2, PE per k-step
+#pragma unroll
+                        for (int j = 0; j < PE; ++j)
+                            if (e * PE + j < P) stage_piece(cstage, bstage, e * PE + j);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (!LASTD) wait_vm_chunk<P>(an);
+        }
+        {   // drain: the last A dwords and DMA pieces are in flight and never used; keep their registers tied up
+            float sink = 0.0f;
 #pragma unroll
             for (int gl = 0; gl < G; ++gl)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ac[gl][e] = an[gl][e];
+                for (int e = 0; e < 4; ++e) { wait_vm1<0>(av[gl][e]); sink += av[gl][e]; }
+            if (a.tiles < 0) a.out[0] = sink;  // never true
         }
-        dma_wait_all();  // the last (redundant) DMA pieces, before compiler-visible memory traffic
 
         // ---- epilogue: bias/activation (forward) or act' of the previous layer (data gradient).
         // vmcnt counts stores as well as loads, in issue order: a load issued after a store cannot be
