@@ -115,6 +115,20 @@ def cpu_baseline(cfg, seconds):
                       % (steps, cfg["B"], dt, torch.__version__, cores)}
 
 
+def measured_traffic(kind):
+    """HBM bytes per launch of the dominant GEMM kernel from the committed counter passes (profiles/r01_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied); None if the file is absent."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    want = {"dense_fwd": "svae::dense_kernel<4, false", "dense_dgrad": "svae::dense_kernel<4, true", "wgrad": "svae::wgrad_kernel"}[kind]
+    for name, d in prof.items():
+        if name.startswith(want):
+            return d.get("hbm_bytes_corrected")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,7 +204,7 @@ def main():
             avg_ms = gemm[dom][0] / gemm[dom][1]
             ach = f_gemm / (avg_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": measured_traffic(dom),
                         "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": f_gemm,
                         "gemm_kernels_avg_ms": {k: round(v[0] / v[1], 4) for k, v in sorted(gemm.items())},
                         "kernels_ms_per_step": breakdown}

@@ -272,7 +272,7 @@ int dense_nt_for(int ntile) {
     static const int cap = [] {
         const char* e = getenv("SVAE_DENSE_NT");
         const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 8;
+        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 4;
     }();
     int nt = 16;
     while (nt > 1 && (ntile % nt != 0 || nt > cap)) nt >>= 1;

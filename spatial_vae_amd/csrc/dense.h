@@ -157,8 +157,18 @@ struct DenseCfg {
     static constexpr int NINSTR = G * NT;              // 1 KiB global_load_lds wave-instructions per chunk
 };
 
+#ifndef SVAE_NT4_WAVES
+#define SVAE_NT4_WAVES 3
+#endif
+// waves per SIMD the register allocation is sized for: 1 at NT = 16 (256 accumulators), 2 at NT = 8, and at
+// NT <= 4 three for the plain kernels (the fused FIRST / LASTD variants keep more values live: two)
+template <int NT, bool FUSED>
+struct DenseOcc {
+    static constexpr int value = NT == 16 ? 1 : (NT == 8 || FUSED) ? 2 : SVAE_NT4_WAVES;
+};
+
 template <int NT, bool DGRAD, bool RESID, bool FIRST = false, bool LASTD = false>
-__global__ __launch_bounds__(256, (NT == 16 ? 1 : 2)) void dense_kernel(DenseArgs a) {
+__global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void dense_kernel(DenseArgs a) {
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(!LASTD || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
     extern __shared__ __attribute__((aligned(16))) float smem[];
