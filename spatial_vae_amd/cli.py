@@ -1,0 +1,219 @@
+"""Shared machinery of the three training command lines (train_mnist.py, train_galaxy.py,
+train_particles.py at the repository root).
+
+The reference triplicates its loop per script (train_mnist.py:127-226 and 268-469, train_galaxy.py:186-294
+and 346-575, train_particles.py:151-245 and 272-547); here ONE loop serves all three and the scripts only
+declare their flag surfaces (which differ: underscores for mnist/galaxy, hyphens for particles).  Kept:
+flag names and defaults, the step order (loss = -elbo; backward; step; zero_grad), the running-mean metric
+arithmetic, the stdout tables, train.txt / val.txt / command.txt / models.txt, and the whole-module
+`.sav` checkpoints with the reference's file names.  Dropped (out of scope): the
+interactive "clear outputs?" prompt (the run directory is created, never wiped), PNG/SVG dumps, the zip
+archive, dataset download, MRC input and PIL rotation augmentation (both raise).  Added: `--synthetic N`
+(train on N synthetic images when no data files exist), data-parallel execution under torchrun, and
+`--progress_every` (the reference pays three .item() syncs per step for its progress line).
+"""
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dp
+from . import elbo as E
+
+
+class RunningMean(object):
+    """acc += b * (v - acc) / count  (train_mnist.py:156-164), kept on the device in float64."""
+
+    def __init__(self, device, n=3):
+        self.acc = torch.zeros(n, dtype=torch.float64, device=device)
+        self.count = 0
+
+    def update(self, batch_size, values):
+        self.count += batch_size
+        v = torch.stack([x.detach().double() for x in values])
+        self.acc += batch_size * (v - self.acc) / self.count
+
+    def values(self):
+        return [float(x) for x in self.acc.cpu()]
+
+
+def coord_grid(n_rows, n_cols):
+    """(N, 2) grid of train_mnist.py:315-320."""
+    x0, x1 = np.meshgrid(np.linspace(-1, 1, n_cols), np.linspace(1, -1, n_rows))
+    return torch.from_numpy(np.stack([x0.ravel(), x1.ravel()], 1)).float()
+
+
+def activation_class(script, name):
+    """The scripts' (inconsistent) flag-to-module maps: 'relu' means LeakyReLU in mnist/particles
+    (train_mnist.py:344-348, train_particles.py:433-436) but nn.ReLU in galaxy, where 'leakyrelu' is
+    mis-spelt in the reference and silently gives Tanh (train_galaxy.py:426-434)."""
+    if script == "galaxy":
+        return {"tanh": nn.Tanh, "relu": nn.ReLU, "sigmoid": nn.Sigmoid}.get(name, nn.Tanh)
+    return nn.Tanh if name == "tanh" else nn.LeakyReLU
+
+
+def pick_device(d):
+    """-d/--device: -1 = CPU, >= 0 = that GPU, -2 (default) = GPU if there is one (train_mnist.py:323-327).
+    The MI355X decoder has no CPU path, so a CPU request is refused up front."""
+    rank, world, local = dp.env_world()
+    if d == -1 or not torch.cuda.is_available():
+        raise SystemExit("spatial_vae_amd: the decoder runs on an MI355X only (-d -1 / no GPU is not supported)")
+    idx = d if d >= 0 else local
+    if world > 1:
+        idx = local
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
+
+
+def make_run_dir(prefix, args):
+    out = "outputs_{}".format(prefix)
+    trained = os.path.join(out, "trained")
+    os.makedirs(trained, exist_ok=True)
+    os.makedirs(os.path.join(out, "images"), exist_ok=True)
+    with open(os.path.join(out, "command.txt"), "w") as f:
+        for k, v in sorted(vars(args).items()):
+            print("{}: {}".format(k, v), file=f)
+    return out, trained
+
+
+def save_models(path_prefix, epoch_str, p_net, q_net, device):
+    """torch.save(<whole module>) under the reference's names (src/misc_tools.py:88-104)."""
+    for tag, net in (("generator", p_net), ("inference", q_net)):
+        sinks = net.__dict__.pop("_grad_sinks", None)       # views into a training buffer: not part of the model
+        net.eval().cpu()
+        torch.save(net, "{}_{}_epoch{}.sav".format(path_prefix, tag, epoch_str))
+        net.to(device)
+        if sinks is not None:
+            net._grad_sinks = sinks
+
+
+def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world, progress_every, extra):
+    """One pass over `batches` (a list of index tensors into the resident data).  Training uses
+    dp.TrainStep (forward, backward, all-reduce, Adam); evaluation only the forward (it is stochastic in
+    the reference too: eval_model draws noise, train_mnist.py:174-226)."""
+    p_net, q_net = step.p_net, step.q_net
+    p_net.train(train)
+    q_net.train(train)
+    data = extra["data"]
+    mean = RunningMean(x.device)
+    for it, idx in enumerate(batches):
+        gb = idx.numel()
+        lo, hi = dp.shard_bounds(gb, rank, world)
+        sel = idx[lo:hi]
+        y = data["y"][sel]
+        args = (y,)
+        if script == "particles":
+            ctf = data["ctf"][sel] if data.get("ctf") is not None else None
+            args = (y, extra.get("mask"), ctf)
+        kw = dict(extra.get("kw", {}))
+        if train:
+            out = step(x, *args, weight=(hi - lo) / gb, **kw)
+        else:
+            with torch.no_grad():
+                call = dict(step.eval_kwargs)
+                call.update(kw)
+                out = step.eval_minibatch(x, *args, p_net, q_net, **call)
+        elbo, log_p, kl = out[0], out[1], out[2]
+        vals = torch.stack([elbo.detach(), -log_p.detach(), kl.detach()]) * ((hi - lo) / gb)
+        if world > 1:
+            torch.distributed.all_reduce(vals)
+        mean.update(gb, list(vals))
+        if train and rank == 0 and progress_every > 0 and (it + 1) % progress_every == 0:
+            e, g, k = mean.values()
+            print("# [{}/{}] training {:.1%}, ELBO={:.5f}, Error={:.5f}, KL={:.5f}".format(
+                epoch + 1, num_epochs, mean.count / N, e, g, k), end="\r", file=sys.stderr)
+    if train and rank == 0 and progress_every > 0:
+        print(" " * 80, end="\r", file=sys.stderr)
+    return mean.values()
+
+
+def train_main(script, args, build):
+    """`build(args, device)` returns dict(y_train, y_test, ctf_train, ctf_test, mask, n, m, channels,
+    p_net, q_net, rotate, translate, table)."""
+    rank, world, _ = dp.init_process_group(device_is_gpu=True)
+    device = pick_device(args.device)
+    start = time.time()
+    prefix = args.save_prefix
+    out_dir = trained = None
+    if script != "particles":
+        if prefix is None:
+            raise SystemExit("--save_prefix is required (the reference crashes without it: src/misc_tools.py:22)")
+        if rank == 0:
+            out_dir, trained = make_run_dir(prefix, args)
+    cfg = build(args, device)
+    p_net, q_net = cfg["p_net"].to(device), cfg["q_net"].to(device)
+    if rank == 0 and out_dir:
+        with open(os.path.join(out_dir, "models.txt"), "w") as f:
+            print(p_net, file=f)
+            print(q_net, file=f)
+    x = coord_grid(cfg["n"], cfg["m"]).to(device)
+    fn = {"mnist": E.eval_minibatch_mnist, "galaxy": E.eval_minibatch_galaxy, "particles": E.eval_minibatch_particles}[script]
+    step = dp.TrainStep(p_net, q_net, fn, lr=args.learning_rate, rotate=cfg["rotate"], translate=cfg["translate"],
+                        dx_scale=args.dx_scale, theta_prior=args.theta_prior)
+    print("# using priors: theta={}, dx={}".format(args.theta_prior, args.dx_scale), file=sys.stderr)
+    num_epochs = args.num_epochs
+    digits = int(math.log10(num_epochs)) + 1
+    bs = args.minibatch_size
+    tr = {"y": cfg["y_train"].to(device), "ctf": None if cfg.get("ctf_train") is None else cfg["ctf_train"].to(device)}
+    te = {"y": cfg["y_test"].to(device), "ctf": None if cfg.get("ctf_test") is None else cfg["ctf_test"].to(device)}
+    mask = cfg.get("mask")
+    mask = mask.to(device) if mask is not None else None
+    N = tr["y"].size(0)
+    gen = torch.Generator()
+    gen.manual_seed(torch.initial_seed())
+    out = sys.stdout
+    header = cfg["table"]
+    if rank == 0:
+        print("\t".join(header), file=out)
+    train_lines, val_lines = ["\t".join(header)], ["\t".join(header)]
+    z_delay = getattr(args, "z_delay", 0)
+    for epoch in range(num_epochs):
+        kw = {}
+        if script != "mnist":
+            kw["z_scale"] = 0 if epoch < z_delay else 1
+        perm = torch.randperm(N, generator=gen)                      # DataLoader(shuffle=True): same order on every rank
+        batches = [perm[i:i + bs].to(device) for i in range(0, N, bs)]
+        e, g, k = run_epoch(script, step, x, batches, True, N, epoch, num_epochs, rank, world, args.progress_every,
+                            dict(data=tr, mask=mask, kw=kw))
+        ntest = te["y"].size(0)
+        order = torch.arange(ntest)
+        tb = [order[i:i + bs].to(device) for i in range(0, ntest, bs)]
+        ev = run_epoch(script, step, x, tb, False, ntest, epoch, num_epochs, rank, world, 0, dict(data=te, mask=mask, kw=kw))
+        if rank == 0:
+            if script == "particles":
+                print("\t".join([str(epoch + 1), "train", str(e), str(g), str(k)]), file=out)
+                print("\t".join([str(epoch + 1), "test", str(ev[0]), str(ev[1]), str(ev[2])]), file=out)
+            else:
+                line = "\t".join(map(str, [epoch, e, g, k]))
+                train_lines.append(line)
+                print(line, file=out)
+                line = "\t".join(map(str, [epoch, ev[0], ev[1], ev[2]]))
+                val_lines.append(line)
+                print(line, file=out)
+            out.flush()
+            if script == "particles" and prefix is not None and (epoch + 1) % args.save_interval == 0:
+                save_models(prefix, str(epoch + 1).zfill(digits), p_net, q_net, device)
+    if rank == 0 and script != "particles":
+        save_models(os.path.join(trained, prefix), str(num_epochs).zfill(digits), p_net, q_net, device)
+        with open(os.path.join(out_dir, "train.txt"), "w") as f:
+            print("\n".join(train_lines), file=f)
+        with open(os.path.join(out_dir, "val.txt"), "w") as f:
+            print("\n".join(val_lines), file=f)
+        print("Elapsed time: {:.1f} s".format(time.time() - start))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+def synthetic_images(kind, count, n, m, channels, seed):
+    rs = np.random.RandomState(seed)
+    if kind == "particles":
+        return rs.normal(size=(count, n, m)).astype(np.float32)
+    shape = (count, n, m) if channels == 1 else (count, n, m, channels)
+    u = rs.uniform(size=shape)
+    keep = rs.uniform(size=shape) > (0.8 if channels == 1 else 0.0)
+    return np.floor(u * keep * 255.0).astype(np.float32)

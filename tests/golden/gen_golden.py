@@ -171,6 +171,8 @@ def run_case(case):
 
 
 def main():
+    if "--ctf" in sys.argv:
+        return
     names = sys.argv[1:] or [c["name"] for c in C.CASES]
     torch.set_num_threads(4)
     total = 0
@@ -187,3 +189,22 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def gen_ctf_fixture():
+    """Reference CTF filter bank (spatial_vae/ctf.py:33-56) on a small seeded parameter table."""
+    ref_ctf = _load("ref_ctf", os.path.join(REF, "spatial_vae", "ctf.py"))
+    rs = np.random.RandomState(5)
+    tab = np.stack([rs.uniform(1, 3, 6), np.full(6, 2.7), np.full(6, 300.0), rs.uniform(1.0, 2.5, 6), np.full(6, 100.0),
+                    np.full(6, 10.0), np.zeros(6), rs.uniform(0, 180, 6)], 1)
+    path = os.path.join(HERE, "ctf_table.txt")
+    np.savetxt(path, tab)
+    out = {"table": tab}
+    for n, m, scale in ((9, 9, 1), (15, 13, 2)):
+        out["filt_%dx%d_s%d" % (n, m, scale)] = ref_ctf.ctf_filter(ref_ctf.parse_ctf(path), n, m, scale=scale)
+    np.savez_compressed(os.path.join(HERE, "ctf_golden.npz"), **out)
+    print("ctf fixture written")
+
+
+if __name__ == "__main__" and "--ctf" in sys.argv:
+    gen_ctf_fixture()

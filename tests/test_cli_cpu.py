@@ -1,0 +1,88 @@
+"""CPU checks of the command-line layer: flag surfaces equal to the reference's,
+the running-mean metric arithmetic, the host CTF filter generator against a fixture made by the reference."""
+import os
+
+import numpy as np
+import torch
+
+from helpers import GOLDEN_DIR
+
+
+def _dests(ns):
+    return set(vars(ns).keys())
+
+
+def test_mnist_flag_surface_and_defaults():
+    import train_mnist
+    a = train_mnist.mnist_arguments(["--save_prefix", "p"])
+    # /root/reference/train_mnist.py:232-263 (underscore spellings)
+    want = {"dataset", "z_dim", "p_hidden_dim", "q_hidden_dim", "num_layers", "activation", "vanilla", "no_rotate",
+            "no_translate", "dx_scale", "theta_prior", "learning_rate", "minibatch_size", "save_prefix", "save_interval",
+            "num_epochs", "device", "num_train_images", "val_split"}
+    assert want <= _dests(a)
+    assert (a.dataset, a.z_dim, a.p_hidden_dim, a.q_hidden_dim, a.num_layers, a.activation) == \
+        ("mnist-rotated-translated", 2, 500, 500, 2, "tanh")
+    assert abs(a.theta_prior - np.pi / 4) < 1e-12 and a.dx_scale == 0.1 and a.learning_rate == 1e-4
+    assert (a.minibatch_size, a.save_interval, a.num_epochs, a.device) == (100, 10, 100, -2)
+
+
+def test_galaxy_flag_surface_and_defaults():
+    import train_galaxy
+    a = train_galaxy.galaxy_arguments(["tr.npy", "te.npy"])
+    want = {"train_path", "test_path", "z_dim", "p_hidden_dim", "p_num_layers", "q_hidden_dim", "q_num_layers", "activation",
+            "vanilla", "no_rotate", "no_translate", "dx_scale", "theta_prior", "learning_rate", "minibatch_size",
+            "augment_rotation", "z_delay", "save_prefix", "save_interval", "num_epochs", "device", "num_train_images",
+            "val_split", "make_mono", "logging_level", "invert_colours"}
+    assert want <= _dests(a)
+    assert (a.q_hidden_dim, a.p_hidden_dim, a.p_num_layers, a.q_num_layers) == (5000, 500, 2, 2)   # train_galaxy.py:304-307
+    assert abs(a.theta_prior - np.pi) < 1e-12
+
+
+def test_particles_flag_surface_uses_hyphens():
+    import train_particles
+    a = train_particles.particle_arguments(["tr.npy", "te.npy", "--fit-noise", "--no-translate", "--z-dim", "8", "--ctf-train", "t.txt",
+                                            "--p-hidden-dim", "64", "--minibatch-size", "7", "--expand-coords", "--bilinear",
+                                            "--resid", "--softplus", "--mask", "--normalize", "-c", "32"])
+    assert a.fit_noise and a.no_translate and a.z_dim == 8 and a.ctf_train == "t.txt" and a.p_hidden_dim == 64
+    assert a.minibatch_size == 7 and a.expand_coords and a.bilinear and a.resid and a.softplus and a.mask and a.crop == 32
+    assert abs(a.theta_prior - np.pi) < 1e-12 and a.scale == 1
+
+
+def test_activation_maps_follow_the_scripts_quirks():
+    import torch.nn as nn
+    from spatial_vae_amd import cli
+    assert cli.activation_class("mnist", "relu") is nn.LeakyReLU          # train_mnist.py:344-348
+    assert cli.activation_class("particles", "relu") is nn.LeakyReLU      # train_particles.py:433-436
+    assert cli.activation_class("galaxy", "relu") is nn.ReLU              # train_galaxy.py:431-432
+    assert cli.activation_class("galaxy", "leakyrelu") is nn.Tanh         # the reference's mis-spelt branch, :429
+
+
+def test_running_mean_matches_reference_arithmetic():
+    from spatial_vae_amd.cli import RunningMean
+    rs = np.random.RandomState(0)
+    sizes = [100, 100, 37]
+    vals = rs.normal(size=(3, 3))
+    acc, count = np.zeros(3), 0
+    rm = RunningMean(torch.device("cpu"))
+    for b, v in zip(sizes, vals):
+        count += b
+        acc += b * (v - acc) / count                                        # train_mnist.py:156-164
+        rm.update(b, [torch.tensor(x) for x in v])
+    assert np.allclose(rm.values(), acc, rtol=0, atol=1e-12)
+
+
+def test_coord_grid_matches_case_builder():
+    import cases as C
+    from spatial_vae_amd.cli import coord_grid
+    assert np.array_equal(coord_grid(9, 5).numpy(), C.coord_grid(9, 5))
+
+
+def test_ctf_filter_matches_reference_fixture():
+    from spatial_vae_amd import ctf as C
+    with np.load(os.path.join(GOLDEN_DIR, "ctf_golden.npz")) as f:
+        gold = {k: f[k] for k in f.files}
+    params = C.parse_ctf(os.path.join(GOLDEN_DIR, "ctf_table.txt"))
+    for key, (n, m, s) in {"filt_9x9_s1": (9, 9, 1), "filt_15x13_s2": (15, 13, 2)}.items():
+        got = C.ctf_filter(params, n, m, scale=s)
+        assert got.shape == gold[key].shape
+        assert np.abs(got - gold[key]).max() <= 1e-7 * np.abs(gold[key]).max()

@@ -1,0 +1,59 @@
+"""End-to-end runs of the three command lines on synthetic data (GPU)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, args, cwd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, cwd=cwd, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    return [l for l in out.stdout.splitlines() if "\t" in l]
+
+
+def test_train_mnist_cli(tmp_path):
+    rows = _run("train_mnist.py", ["--synthetic", "300", "--num_epochs", "2", "--minibatch_size", "64", "--p_hidden_dim", "64",
+                                   "--q_hidden_dim", "32", "--save_prefix", "t", "--progress_every", "0"], str(tmp_path))
+    assert rows[0].split("\t") == ["Epoch", "ELBO", "BCE loss", "KL"]
+    assert len(rows) == 1 + 2 * 2                                     # train + val line per epoch
+    vals = [[float(x) for x in r.split("\t")] for r in rows[1:]]
+    assert all(np.isfinite(v).all() for v in vals)
+    assert vals[2][1] > vals[0][1]                                    # training ELBO improves epoch 0 -> 1
+    out = tmp_path / "outputs_t"
+    for f in ("train.txt", "val.txt", "command.txt", "models.txt", "trained/t_generator_epoch2.sav", "trained/t_inference_epoch2.sav"):
+        assert (out / f).exists(), f
+    p = torch.load(out / "trained" / "t_generator_epoch2.sav", weights_only=False)       # a file this test just wrote
+    assert type(p).__name__ == "SpatialGenerator" and "coord_linear.weight" in p.state_dict()
+
+
+def test_train_galaxy_cli(tmp_path):
+    rows = _run("train_galaxy.py", ["x", "y", "--synthetic", "64", "--num_epochs", "1", "--minibatch_size", "32", "--p_hidden_dim", "32",
+                                    "--q_hidden_dim", "32", "--p_num_layers", "3", "-z", "4", "--save_prefix", "g", "--progress_every",
+                                    "0"], str(tmp_path))
+    assert rows[0].split("\t") == ["Epoch", "ELBO", "BCE loss", "KL"] and len(rows) == 3
+
+
+def test_train_particles_cli(tmp_path):
+    rs = np.random.RandomState(0)
+    tab = np.stack([rs.uniform(1, 3, 96), np.full(96, 2.7), np.full(96, 300.0), np.full(96, 1.7), np.full(96, 100.0),
+                    np.full(96, 10.0), np.zeros(96), rs.uniform(0, 180, 96)], 1)
+    np.savetxt(tmp_path / "ctf_tr.txt", tab)
+    np.savetxt(tmp_path / "ctf_te.txt", tab[:24])
+    rows = _run("train_particles.py", ["x", "y", "--synthetic", "96", "--num-epochs", "2", "--minibatch-size", "48", "--p-hidden-dim", "32",
+                                       "--q-hidden-dim", "32", "--ctf-train", "ctf_tr.txt", "--ctf-test", "ctf_te.txt", "--mask",
+                                       "--save-prefix", "part", "--save-interval", "2", "--progress-every", "0"], str(tmp_path))
+    assert rows[0].split("\t") == ["Epoch", "Split", "ELBO", "Error", "KL"]
+    assert [r.split("\t")[1] for r in rows[1:]] == ["train", "test", "train", "test"]
+    assert (tmp_path / "part_generator_epoch2.sav").exists() and (tmp_path / "part_inference_epoch2.sav").exists()
+    rows = _run("train_particles.py", ["x", "y", "--synthetic", "64", "--num-epochs", "1", "--minibatch-size", "32", "--p-hidden-dim", "32",
+                                       "--q-hidden-dim", "32", "--fit-noise", "--expand-coords", "--bilinear", "--resid", "--softplus",
+                                       "-a", "relu", "--progress-every", "0"], str(tmp_path))
+    assert len(rows) == 3
