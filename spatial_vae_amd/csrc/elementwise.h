@@ -79,13 +79,21 @@ __global__ void layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ pose
     const int oimg = g.Npad >> 3;
     const int b = (int)(o / oimg);
     const int i0 = ((int)(o - (long)b * oimg) << 3) + 4 * h;
-    const float4 pb = posebuf[b];
+    const float4 pb = posebuf[b];  // identity (1, 0, 0, 0) when the coordinates are explicit
     const float4* tp = reinterpret_cast<const float4*>(tab + ((long)b * g.Hp + k) * kSlots);
     const float4 t0 = tp[0], t1 = tp[1];
+    // the four rows' coordinates: independent loads, no branches (pad rows re-read row N-1 and are zeroed)
+    const float* cbase = pose.coords ? pose.coords + (long)b * g.N * 2 : pose.grid;
+    float2 raw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) raw[e] = *reinterpret_cast<const float2*>(cbase + (long)(i0 + e < g.N ? i0 + e : g.N - 1) * 2);
     float out[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float2 x = row_coord(pose, pb, b, i0 + e, g.N);
+        const bool in = i0 + e < g.N;
+        float2 x;
+        x.x = in ? pb.x * raw[e].x - pb.y * raw[e].y + pb.z : 0.0f;
+        x.y = in ? pb.y * raw[e].x + pb.x * raw[e].y + pb.w : 0.0f;
         float v = t1.y + x.x * t0.x + x.y * t0.y;
         if (g.in_dim == 5) v += (x.x * x.x) * t0.z + (x.y * x.y) * t0.w + (x.x * x.y) * t1.x;
         out[e] = act_fwd<ACT>(v);
