@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph (single GPU; implies --no-profile)")
     args = ap.parse_args()
 
     from spatial_vae_amd import _lib, dp
@@ -164,6 +165,11 @@ def main():
         for i in range(k):
             step(x, pool[i % len(pool)])
 
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU")
+        args.no_profile = True
+        step.capture(x, pool[0])
     run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:

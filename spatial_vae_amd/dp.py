@@ -121,9 +121,12 @@ class TrainStep(object):
         if fused_adam is None:
             fused_adam = on_gpu
         kw = {"fused": True} if fused_adam else {}
+        if on_gpu:
+            kw["capturable"] = True      # step counter on the device: lets the whole step live in a HIP graph
         self.optim = torch.optim.Adam([self.master], lr=lr, **kw)
+        self._graph = None
 
-    def __call__(self, x, *batch, weight=1.0, **kw):
+    def _step(self, x, batch, weight, kw):
         args = dict(self.eval_kwargs)
         args.update(kw)
         out = self.eval_minibatch(x, *batch, self.p_net, self.q_net, **args)
@@ -133,3 +136,40 @@ class TrainStep(object):
         self.optim.step()
         self.grads.zero()
         return out
+
+    def __call__(self, x, *batch, weight=1.0, **kw):
+        if self._graph is not None:
+            return self._replay(x, batch, weight, kw)
+        return self._step(x, batch, weight, kw)
+
+    # ---- optional: the whole step as one HIP graph (single-GPU, fixed shapes) ------------------------
+    def capture(self, x, *batch, warmup=3, **kw):
+        """Record forward + backward + Adam for inputs of these shapes into a HIP graph (torch.cuda.CUDAGraph:
+        the C-ABI launches go to the capture stream like any torch op).  Afterwards __call__ copies the batch
+        into the static input buffers and replays: ~60 kernel launches become one.  Noise is drawn inside the
+        graph from torch's graph-safe Philox generator, as the reference draws it on the device."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("graph capture is wired for the single-GPU step only")
+        self._static_x = x
+        self._static_batch = [b.clone() if torch.is_tensor(b) else b for b in batch]
+        self._static_kw = dict(kw)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step(x, self._static_batch, 1.0, self._static_kw)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_out = self._step(x, self._static_batch, 1.0, self._static_kw)
+        self._graph = g
+        return self
+
+    def _replay(self, x, batch, weight, kw):
+        if weight != 1.0 or kw:
+            raise RuntimeError("a captured step replays fixed arguments")
+        for dst, src in zip(self._static_batch, batch):
+            if torch.is_tensor(dst) and src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._static_out
