@@ -155,8 +155,8 @@ def main():
     p_net, q_net = build_nets(cfg)
     p_net.to(dev)
     q_net.to(dev)
-    step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=cfg["lr"], rotate=True, translate=True,
-                        dx_scale=cfg["dx_scale"], theta_prior=cfg["theta_prior"])
+    step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=cfg["lr"], fused_adam=True if args.graph else None,
+                        rotate=True, translate=True, dx_scale=cfg["dx_scale"], theta_prior=cfg["theta_prior"])
     x = torch.from_numpy(coord_grid(cfg["n"], cfg["m"])).to(dev)
     rs = np.random.RandomState(1000 + rank)
     pool = [torch.from_numpy(synthetic_batch(rs, cfg["B"], N)).to(dev) for _ in range(4)]

@@ -196,6 +196,17 @@ int svae_latent_backward(const svae_latent_desc* d, const float* q_out, const fl
                          svae_stream_t stream);
 
 /*
+ * One Adam update over a flat fp32 parameter buffer: the arithmetic of torch.optim.Adam (amsgrad off, no weight
+ * decay) as the reference uses it (optim = torch.optim.Adam(params, lr=lr); optim.step(), train_mnist.py:389,
+ * 149), element-wise:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *                      p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+ * `step` is t (1 for the first update).  ATen's fused multi-tensor kernel gives one flat tensor of 0.9 M
+ * elements only 14 thread blocks (98 us on MI355X); this is a plain grid over the elements (~5 us).
+ */
+int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t step, svae_stream_t stream);
+
+/*
  * Optional per-kernel timing (bench.py's roofline figure).  While enabled (on = 1: only the three MFMA
  * GEMM kernels, on = 2: every kernel, 0 = off), kernel launches of
  * this library are bracketed by two HIP events recorded on the launch stream; svae_profile_read

@@ -16,7 +16,7 @@ FLAG_RESID, FLAG_BILINEAR, FLAG_SOFTPLUS = 1, 2, 4
 EXPORTS = ("svae_abi_version", "svae_last_error", "svae_saved_bytes", "svae_workspace_bytes",
            "svae_decoder_forward", "svae_decoder_backward", "svae_bce_loglik",
            "svae_gaussian_workspace_bytes", "svae_gaussian_loglik", "svae_profile_enable", "svae_profile_read",
-           "svae_profile_kind_name", "svae_latent_forward", "svae_latent_backward")
+           "svae_profile_kind_name", "svae_latent_forward", "svae_latent_backward", "svae_adam_step")
 PROF_KINDS = 16
 
 
@@ -82,6 +82,9 @@ def lib():
     L.svae_latent_forward.argtypes = [ctypes.POINTER(LatentDesc), vp, vp, vp, vp, vp, vp, vp]
     L.svae_latent_backward.restype = ctypes.c_int
     L.svae_latent_backward.argtypes = [ctypes.POINTER(LatentDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    L.svae_adam_step.restype = ctypes.c_int
+    L.svae_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_float, ctypes.c_int64, vp]
     L.svae_profile_enable.restype = ctypes.c_int
     L.svae_profile_enable.argtypes = [ctypes.c_int]
     L.svae_profile_read.restype = ctypes.c_int

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -162,10 +163,10 @@ int check_ws(const Plan& p, const void* ws, size_t ws_bytes) {
 
 // ---- opt-in per-kernel timing with HIP events (svae_profile_*)
 enum Kind { K_PREPARE = 0, K_LAYER0_FWD, K_DENSE_FWD, K_OUT_FWD, K_DLOGITS, K_OUT_BWD, K_WGRAD, K_WGRAD_REDUCE,
-            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_COUNT };
+            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_ADAM, K_COUNT };
 const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense_fwd", "out_fwd", "dlogits", "out_bwd",
                                                  "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
-                                                 "gaussian", "latent", "", ""};
+                                                 "gaussian", "latent", "adam", ""};
 struct ProfRec { hipEvent_t a, b; int kind; };
 std::mutex g_prof_mu;
 int g_prof_level = 0;  // 0 off, 1 = the three MFMA GEMM kernels only, 2 = every kernel
@@ -623,6 +624,20 @@ int svae_latent_backward(const svae_latent_desc* d, const float* q_out, const fl
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(blocks_for((long)g.B * g.inf)), dim3(256), 0, st, q_out, r, g_theta, g_dx,
                        g_zc, g_kl, g_q_out, g);
     return launch_status("svae_latent_backward");
+}
+
+int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t step, svae_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return fail(SVAE_E_INVALID, "svae_adam_step: bad arguments");
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
+        return fail(SVAE_E_INVALID, "svae_adam_step: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_ADAM, st);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (long)n,
+                       (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, eps);
+    return launch_status("svae_adam_step");
 }
 
 int svae_profile_enable(int on) {

@@ -636,4 +636,34 @@ __global__ void latent_bwd_kernel(const float* __restrict__ q, const float* __re
     gq[(long)b * 2 * g.inf + g.inf + j] = dz * r[idx] * sd + dls;
 }
 
+// ---------------------------------------------------------------- Adam over a flat buffer (A7: optim.step())
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float step_size, float sqrt_bc2, float b1, float b2, float eps) {
+    // operation order of ATen's Adam: denom = sqrt(v) / sqrt(bc2) + eps;  p += (-step_size) * (m / denom)
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+        float4 m4 = *reinterpret_cast<float4*>(m + i), v4 = *reinterpret_cast<float4*>(v + i), p4 = *reinterpret_cast<float4*>(p + i);
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mm[e] = b1 * mm[e] + (1.0f - b1) * gg[e];
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
+            pp[e] += -step_size * (mm[e] / (sqrtf(vv[e]) / sqrt_bc2 + eps));
+        }
+        *reinterpret_cast<float4*>(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    } else {
+        for (long j = i; j < n; ++j) {
+            const float gj = g[j];
+            const float mj = b1 * m[j] + (1.0f - b1) * gj, vj = b2 * v[j] + (1.0f - b2) * gj * gj;
+            m[j] = mj;
+            v[j] = vj;
+            p[j] += -step_size * (mj / (sqrtf(vj) / sqrt_bc2 + eps));
+        }
+    }
+}
+
 }  // namespace svae

@@ -118,12 +118,12 @@ class TrainStep(object):
             p_net._grad_sinks = self.grads.sinks
         self.master = torch.nn.Parameter(self.grads.flat_param)
         self.master.grad = self.grads.flat
-        if fused_adam is None:
-            fused_adam = on_gpu
-        kw = {"fused": True} if fused_adam else {}
-        if on_gpu:
-            kw["capturable"] = True      # step counter on the device: lets the whole step live in a HIP graph
-        self.optim = torch.optim.Adam([self.master], lr=lr, **kw)
+        if on_gpu and fused_adam is None:
+            from .ops import FlatAdam    # torch.optim.Adam's arithmetic in one small kernel over the flat buffer
+            self.optim = FlatAdam([self.master], lr=lr)
+        else:
+            kw = {"fused": True, "capturable": True} if (fused_adam and on_gpu) else {}
+            self.optim = torch.optim.Adam([self.master], lr=lr, **kw)
         self._graph = None
 
     def _step(self, x, batch, weight, kw):
@@ -144,7 +144,8 @@ class TrainStep(object):
 
     # ---- optional: the whole step as one HIP graph (single-GPU, fixed shapes) ------------------------
     def capture(self, x, *batch, warmup=3, **kw):
-        """Record forward + backward + Adam for inputs of these shapes into a HIP graph (torch.cuda.CUDAGraph:
+        """(Needs TrainStep(..., fused_adam=True): torch's capturable Adam keeps its step counter on the device.)
+        Record forward + backward + Adam for inputs of these shapes into a HIP graph (torch.cuda.CUDAGraph:
         the C-ABI launches go to the capture stream like any torch op).  Afterwards __call__ copies the batch
         into the static input buffers and replays: ~60 kernel launches become one.  Noise is drawn inside the
         graph from torch's graph-safe Philox generator, as the reference draws it on the device."""

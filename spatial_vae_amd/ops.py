@@ -159,7 +159,15 @@ class _Decoder(torch.autograd.Function):
                                                ctypes.byref(grads), _p(g_z), ctypes.byref(pg), ws.data_ptr(), ws.numel(),
                                                _stream(device)))
         ctx.saved_buf = None
-        return (None, None, None, g_coords, None, g_theta, g_dx, g_z, g_cw, g_cb, g_lw, g_bw, g_ow, g_ob) + g_hidden
+
+        def ret(t, key):
+            """A gradient the kernels wrote straight into the caller's sink is not handed to autograd again
+            (it would clone the view and, were .grad the same view, add it to itself)."""
+            return None if (t is not None and sinks.get(key) is t) else t
+
+        return (None, None, None, g_coords, None, g_theta, g_dx, g_z, ret(g_cw, "coord_w"), ret(g_cb, "coord_b"),
+                ret(g_lw, "latent_w"), ret(g_bw, "bilinear_w"), ret(g_ow, "out_w"), ret(g_ob, "out_b")) + \
+            tuple(ret(h, "hidden%d" % i) for i, h in enumerate(g_hidden))
 
 
 def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, sinks=None):
@@ -274,3 +282,33 @@ class _GaussianLoglik(torch.autograd.Function):
 
 def gaussian_loglik(y_params, target, mask=None, ctf=None):
     return _GaussianLoglik.apply(y_params, target, mask, ctf)
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam's update (amsgrad off, no weight decay) for ONE flat fp32 CUDA parameter, executed by
+    svae_adam_step.  Same defaults and state names (step, exp_avg, exp_avg_sq) as torch.optim.Adam."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        L = _lib.lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _require_hip(p, "FlatAdam parameter")
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("FlatAdam needs contiguous fp32 parameters and gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                with torch.cuda.device(p.device):
+                    _lib.check(L.svae_adam_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                                st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"], b1, b2, group["eps"],
+                                                st["step"], _stream(p.device)))

@@ -107,3 +107,54 @@ def test_fused_output_layer_backward_option(name, monkeypatch):
     out_bwd pass (off by default: slower on fp32 MFMA); it must give the same gradients."""
     monkeypatch.setenv("SVAE_FUSE_OUT", "1")
     test_eval_minibatch_matches_reference(name)
+
+
+def test_flat_adam_matches_torch_adam():
+    """svae_adam_step against torch.optim.Adam over several steps (odd length: exercises the scalar tail)."""
+    from spatial_vae_amd.ops import FlatAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    w0 = torch.randn(100003, device=dev)
+    a = torch.nn.Parameter(w0.clone())
+    b = torch.nn.Parameter(w0.clone())
+    oa, ob = FlatAdam([a], lr=1e-3), torch.optim.Adam([b], lr=1e-3)
+    for i in range(5):
+        g = torch.randn_like(w0) * (10.0 ** (i - 2))
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    an, bn = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    assert rel_err(an, bn) < 1e-6
+    # element-wise: within 4 ulp of max(|parameter|, the 5e-3 the five steps can move it) -- the two
+    # implementations order the divisions differently
+    assert (np.abs(an - bn) <= 4 * np.spacing(np.maximum(np.abs(bn), np.float32(5e-3)))).all()
+    assert np.abs(an - w0.cpu().numpy()).max() > 1e-3          # and the parameters did move
+
+
+def test_train_step_updates_match_plain_torch_adam():
+    """dp.TrainStep (flat buffers, gradient sinks, FlatAdam) moves the parameters exactly like the reference's
+    loop body: loss = -elbo; backward; torch.optim.Adam.step (train_mnist.py:147-150)."""
+    import copy
+    from spatial_vae_amd import dp, elbo as E
+    case = C.CASES_BY_NAME["mnist_h500"]
+    inp = C.build_inputs(case)
+    dev = torch.device("cuda:0")
+    p1, q1 = _nets(case, inp, dev)
+    p2, q2 = copy.deepcopy(p1), copy.deepcopy(q1)
+    x = torch.from_numpy(inp["x_coord"]).to(dev)
+    y = torch.from_numpy(inp["y"]).to(dev)
+    r = torch.from_numpy(inp["r"]).to(dev)
+    kw = dict(rotate=True, translate=True, dx_scale=case["dx_scale"], theta_prior=case["theta_prior"])
+    step = dp.TrainStep(p1, q1, E.eval_minibatch_mnist, lr=1e-3, **kw)
+    opt = torch.optim.Adam(list(p2.parameters()) + list(q2.parameters()), lr=1e-3)
+    for _ in range(3):
+        step(x, y, noise=r)
+        elbo = E.eval_minibatch_mnist(x, y, p2, q2, noise=r, **kw)[0]
+        (-elbo).backward()
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(list(p1.named_parameters()) + list(q1.named_parameters()),
+                              list(p2.named_parameters()) + list(q2.named_parameters())):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-5, k

@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSVAE_ABLATE=N tools/dense_ablate.hip -o tools/dense_ablate_N
 #include "../spatial_vae_amd/csrc/api.hip"
 #ifndef NTV
-#define NTV 8
+#define NTV 4
 #endif
 int main() {
     const int Hp = 512, H = 500;
