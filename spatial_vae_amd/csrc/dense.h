@@ -14,20 +14,23 @@
 namespace svae {
 
 // ------------------------------------------------------------------------------------------
-// dense_kernel: OUT(Mp x Hp) = epilogue( IN(Mp x Hp) * Wp ), one 32-row tile per wave.
+// dense_kernel: OUT(Mp x Hp) = epilogue( IN(Mp x Hp) * Wp ), one 32-row tile x (NT*32)-column block per wave.
 //
 // MFMA roles (32x32x2: A lane l -> A[i=l&31][k=l>>5], B lane l -> B[k=l>>5][j=l&31]):
-//   A = row operand: lane (m = l&31, h = l>>5) supplies IN[m][8g + 4h + e] at step (g, e);
-//       one global dword per step, prefetched one octet (4 steps) ahead.
+//   A = row operand: lane (m = l&31, h = l>>5) supplies IN[m][8g + 4h + e] at step (g, e): one global
+//       dword per step, fetched exactly one chunk (16 steps) before its use by an asm load that is
+//       re-issued right behind the MFMA group that consumed the register's previous value.
 //   B = packed weights from LDS: lane (n = l&31, h) reads the 16 bytes W[n][8g + 4h .. +3] with
 //       one ds_read_b128 per 4 steps and column tile; slabs are stored [h][n][4] so that lane l
-//       reads bytes 16*l .. 16*l+15 of a 1 KiB slab: lane-linear, bank-conflict-free.
+//       reads bytes 16*l .. 16*l+15 of a 1 KiB slab: lane-linear, bank-conflict-free.  The fragments of
+//       octet g+1 are read into registers before the MFMAs of octet g are issued.
 //   D: lane (n, h) holds rows m = 8q + 4h + r (q = reg>>2, r = reg&3) of column n, i.e. four
 //       consecutive rows per register quad = one 16-byte octet-major store.
-// A workgroup is 4 waves = 4 consecutive row tiles sharing the weight chunks, which stream
-// L2 -> LDS with global_load_lds (no registers), double-buffered, one barrier per chunk.
-// NT column tiles (NB = 32*NT columns) are accumulated at a time: NT = 16 keeps a full
-// 512-wide layer in 256 accumulator registers at one wave per SIMD.
+// A workgroup is 4 waves = 4 consecutive row tiles of ONE column block (blockIdx.y) sharing the weight
+// chunks (4 contraction octets), which stream L2 -> LDS by LDS-DMA issued from inline asm, double-buffered,
+// one barrier per chunk.  NT = 4 (128 columns, 64 accumulator registers, 3-4 waves per SIMD) is the default:
+// it was fastest once the memory instructions were spread (see the loop), and its work quantum divides
+// BASELINE cfg 2 evenly over the chip (25 passes per SIMD).
 // ------------------------------------------------------------------------------------------
 struct DenseArgs {
     const float* in;    // row operand, octet-major (Mp x Hp)
