@@ -207,6 +207,22 @@ int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float beta2, float eps, int64_t step, svae_stream_t stream);
 
 /*
+ * Rotation augmentation of the observed images before inference: the reference rotates each image of the
+ * minibatch by its own random angle with Pillow, one image at a time on the host (train_galaxy.py:41-54: uint8
+ * images, `im.rotate(360*offset/2/pi, resample=Image.BICUBIC)`; train_particles.py:31-43: float32 images).  This is
+ * the same resampler for a whole batch resident in HBM, bit-identical to Pillow 12.2's Image.rotate.
+ *   y, y_rot  (B, rows*cols, C) fp32, distinct buffers.
+ *   matrix    (B, 6) doubles ON THE DEVICE: the inverse affine coefficients Image.rotate derives from the angle
+ *             (cos/sin of -radians(angle) rounded to 15 decimals, centre (cols/2, rows/2)); ignored where quarter >= 0.
+ *   quarter   (B) int32 on the device: -1 = use the matrix; 0..3 = exact counter-clockwise quarter turns (Pillow's
+ *             fast paths for angle % 360 in {0, 90, 180, 270}).
+ *   quantize_u8 != 0: samples pass through uint8 as in train_galaxy.py:50-53 ((y*255).astype(uint8) in, /255 out);
+ *             0: float32 'F' images as in train_particles.py:40-42.
+ */
+int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, const int32_t* quarter, int32_t B, int32_t rows,
+                        int32_t cols, int32_t C, int32_t quantize_u8, svae_stream_t stream);
+
+/*
  * Optional per-kernel timing (bench.py's roofline figure).  While enabled (on = 1: only the three MFMA
  * GEMM kernels, on = 2: every kernel, 0 = off), kernel launches of
  * this library are bracketed by two HIP events recorded on the launch stream; svae_profile_read

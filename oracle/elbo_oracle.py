@@ -324,13 +324,15 @@ def gaussian_loglik(y_params, target, mask=None, ctf=None):
 # A7: KL terms, ELBO, and the whole minibatch (the three eval_minibatch functions)
 # --------------------------------------------------------------------------
 def elbo_minibatch(script, spec, P, grid, y, q_out, r, rotate=True, translate=True, dx_scale=0.1,
-                   theta_prior=np.pi, z_scale=1.0, mask=None, ctf=None):
+                   theta_prior=np.pi, z_scale=1.0, mask=None, ctf=None, theta_offset=None):
     """One ELBO minibatch from the encoder output onward, with d(-elbo)/d(everything).
 
     script: 'mnist' (train_mnist.py:24-90), 'galaxy' (train_galaxy.py:27-128) or
     'particles' (train_particles.py:22-148).  q_out (B, 2*inf_dim) is the encoder's raw
     output [z_mu | z_logstd] (models.py:50-52); r (B, inf_dim) the N(0,1) draw
     (train_mnist.py:38-39).  Gradients are those of loss = -elbo (train_mnist.py:147-148).
+    theta_offset (B,) float64: the augmentation angles added back to theta (train_galaxy.py:84-87); q_out must then
+    be the encoder's output for the ROTATED images (oracle/pil_rotate.py).
     """
     B = y.shape[0]
     inf = q_out.shape[1] // 2
@@ -344,6 +346,8 @@ def elbo_minibatch(script, spec, P, grid, y, q_out, r, rotate=True, translate=Tr
     s = F32(theta_prior)
     if rotate:
         theta = z[:, 0]
+        if theta_offset is not None and np.any(theta_offset > 0):
+            theta = theta + np.asarray(theta_offset).astype(F32)
         kl = -z_logstd[:, 0] + np.log(s, dtype=F32) + z_std[:, 0] ** 2 / F32(2) / s ** 2 - F32(0.5)
         if script == "mnist":                                                 # train_mnist.py:63 keeps the mu^2 term
             kl = kl + z_mu[:, 0] ** 2 / F32(2) / s ** 2

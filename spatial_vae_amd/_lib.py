@@ -85,6 +85,8 @@ def lib():
     L.svae_adam_step.restype = ctypes.c_int
     L.svae_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_int64, vp]
+    L.svae_rotate_bicubic.restype = ctypes.c_int
+    L.svae_rotate_bicubic.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svae_profile_enable.restype = ctypes.c_int
     L.svae_profile_enable.argtypes = [ctypes.c_int]
     L.svae_profile_read.restype = ctypes.c_int

@@ -8,7 +8,8 @@ flag names and defaults, the step order (loss = -elbo; backward; step; zero_grad
 arithmetic, the stdout tables, train.txt / val.txt / command.txt / models.txt, and the whole-module
 `.sav` checkpoints with the reference's file names.  Dropped (out of scope): the
 interactive "clear outputs?" prompt (the run directory is created, never wiped), PNG/SVG dumps, the zip
-archive, dataset download, MRC input and PIL rotation augmentation (both raise).  Added: `--synthetic N`
+archive, dataset download and MRC input (raises).  `--augment_rotation` runs on the device
+(ops.rotate_augment, bit-identical to the reference's per-image Pillow loop).  Added: `--synthetic N`
 (train on N synthetic images when no data files exist), data-parallel execution under torchrun, and
 `--progress_every` (the reference pays three .item() syncs per step for its progress line).
 """
@@ -111,6 +112,7 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
             args = (y, extra.get("mask"), ctf)
         kw = dict(extra.get("kw", {}))
         if train:
+            kw.update(extra.get("train_kw", {}))        # augmentation applies to training steps only (train_galaxy.py:204)
             out = step(x, *args, weight=(hi - lo) / gb, **kw)
         else:
             with torch.no_grad():
@@ -177,8 +179,9 @@ def train_main(script, args, build):
             kw["z_scale"] = 0 if epoch < z_delay else 1
         perm = torch.randperm(N, generator=gen)                      # DataLoader(shuffle=True): same order on every rank
         batches = [perm[i:i + bs].to(device) for i in range(0, N, bs)]
+        train_kw = {"augment_rotation": True} if cfg.get("augment") and script != "mnist" else {}
         e, g, k = run_epoch(script, step, x, batches, True, N, epoch, num_epochs, rank, world, args.progress_every,
-                            dict(data=tr, mask=mask, kw=kw))
+                            dict(data=tr, mask=mask, kw=kw, train_kw=train_kw))
         ntest = te["y"].size(0)
         order = torch.arange(ntest)
         tb = [order[i:i + bs].to(device) for i in range(0, ntest, bs)]

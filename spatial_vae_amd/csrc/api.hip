@@ -163,10 +163,10 @@ int check_ws(const Plan& p, const void* ws, size_t ws_bytes) {
 
 // ---- opt-in per-kernel timing with HIP events (svae_profile_*)
 enum Kind { K_PREPARE = 0, K_LAYER0_FWD, K_DENSE_FWD, K_OUT_FWD, K_DLOGITS, K_OUT_BWD, K_WGRAD, K_WGRAD_REDUCE,
-            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_ADAM, K_COUNT };
+            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_ADAM, K_AUGMENT, K_COUNT };
 const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense_fwd", "out_fwd", "dlogits", "out_bwd",
                                                  "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
-                                                 "gaussian", "latent", "adam", ""};
+                                                 "gaussian", "latent", "adam", "augment"};
 struct ProfRec { hipEvent_t a, b; int kind; };
 std::mutex g_prof_mu;
 int g_prof_level = 0;  // 0 off, 1 = the three MFMA GEMM kernels only, 2 = every kernel
@@ -638,6 +638,22 @@ int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (long)n,
                        (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, eps);
     return launch_status("svae_adam_step");
+}
+
+int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, const int32_t* quarter, int32_t B, int32_t rows,
+                        int32_t cols, int32_t C, int32_t quantize_u8, svae_stream_t stream) {
+    if (!y || !y_rot || !matrix || !quarter || y == y_rot) return fail(SVAE_E_INVALID, "svae_rotate_bicubic: bad pointers");
+    if (B < 1 || rows < 1 || cols < 1 || C < 1 || (long)B * rows * cols * C > (1L << 40))
+        return fail(SVAE_E_INVALID, "svae_rotate_bicubic: bad sizes B=%d rows=%d cols=%d C=%d", B, rows, cols, C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_AUGMENT, st);
+    const RotGeo g{B, rows, cols, C};
+    const long total = (long)B * rows * cols * C;
+    if (quantize_u8)
+        hipLaunchKernelGGL(rotate_bicubic_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, st, y, y_rot, matrix, quarter, g);
+    else
+        hipLaunchKernelGGL(rotate_bicubic_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, st, y, y_rot, matrix, quarter, g);
+    return launch_status("svae_rotate_bicubic");
 }
 
 int svae_profile_enable(int on) {

@@ -636,6 +636,87 @@ __global__ void latent_bwd_kernel(const float* __restrict__ q, const float* __re
     gq[(long)b * 2 * g.inf + g.inf + j] = dz * r[idx] * sd + dls;
 }
 
+// ---------------------------------------------------------------- rotation augmentation (train_galaxy.py:41-54, train_particles.py:31-43)
+// Pillow's Image.rotate(angle, resample=BICUBIC) for a batch of square-or-not images resident in HBM.  The host supplies,
+// per image, the six inverse-affine coefficients exactly as PIL/Image.py computes them (doubles) or an exact quarter-turn
+// code; the resampler below follows libImaging/Geometry.c (affine_transform + bicubic_filter8/32RGB/32F) operation by
+// operation in doubles with contraction off, so results are bit-identical to Pillow's (oracle/pil_rotate.py is the CPU
+// restatement it is tested against).  U8 = the galaxy/MNIST path: samples are (uint8)(y*255), the result is clamped to
+// [0,255], truncated and returned as (double)q/255 rounded to float, as the reference's astype chain does.
+struct RotGeo {
+    int B, rows, cols, C;
+};
+
+template <bool U8>
+__global__ void rotate_bicubic_kernel(const float* __restrict__ y, float* __restrict__ out, const double* __restrict__ mat,
+                                      const int* __restrict__ quarter, RotGeo g) {
+#pragma clang fp contract(off)
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)g.rows * g.cols * g.C;
+    if (t >= per * g.B) return;
+    const int b = (int)(t / per);
+    const int rem = (int)(t - (long)b * per);
+    const int c = rem % g.C;
+    const int px = (rem / g.C) % g.cols, py = rem / (g.C * g.cols);
+    const float* img = y + (long)b * per;
+    const int w = g.cols, h = g.rows;
+    auto sample = [&](int yy, int xx) -> float { return img[((long)yy * w + xx) * g.C + c]; };
+    const int q = quarter[b];
+    if (q >= 0) {  // exact multiples of 90 degrees: copy / transpose (Image.rotate fast paths), counter-clockwise
+        int sy = py, sx = px;
+        if (q == 1) { sy = px; sx = w - 1 - py; }
+        if (q == 2) { sy = h - 1 - py; sx = w - 1 - px; }
+        if (q == 3) { sy = h - 1 - px; sx = py; }
+        const float v = sample(sy, sx);
+        out[t] = U8 ? (float)((double)(unsigned char)(v * 255.0f) / 255.0) : v;
+        return;
+    }
+    const double* a = mat + (long)b * 6;
+    double xin = (double)px + 0.5, yin = (double)py + 0.5;
+    const double xo = a[0] * xin + a[1] * yin + a[2];
+    const double yo = a[3] * xin + a[4] * yin + a[5];
+    if (xo < 0.0 || xo >= (double)w || yo < 0.0 || yo >= (double)h) {
+        out[t] = 0.0f;
+        return;
+    }
+    xin = xo - 0.5;
+    yin = yo - 0.5;
+    int x = xin < 0.0 ? (int)floor(xin) : (int)xin;
+    int yy = yin < 0.0 ? (int)floor(yin) : (int)yin;
+    const double dx = xin - x, dy = yin - yy;
+    --x;
+    --yy;
+    int xc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xc[k] = min(max(x + k, 0), w - 1);
+    auto horner = [](double p1, double p2, double p3, double p4, double d) { return p1 + d * (p2 + d * (p3 + d * p4)); };
+    auto row = [&](int r) -> double {
+        if (U8) {  // integer coefficient arithmetic, as C promotes UINT8 operands
+            int s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = (int)(unsigned char)(sample(r, xc[k]) * 255.0f);
+            return horner((double)s[1], (double)(-s[0] + s[2]), (double)(2 * (s[0] - s[1]) + s[2] - s[3]),
+                          (double)(-s[0] + s[1] - s[2] + s[3]), dx);
+        }
+        float s[4];  // FLOAT32 operands: the coefficient expressions are float arithmetic
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = sample(r, xc[k]);
+        const float p2 = -s[0] + s[2], p3 = 2.0f * (s[0] - s[1]) + s[2] - s[3], p4 = -s[0] + s[1] - s[2] + s[3];
+        return horner((double)s[1], (double)p2, (double)p3, (double)p4, dx);
+    };
+    const double v1 = row(min(max(yy, 0), h - 1));
+    const double v2 = (yy + 1 >= 0 && yy + 1 < h) ? row(yy + 1) : v1;
+    const double v3 = (yy + 2 >= 0 && yy + 2 < h) ? row(yy + 2) : v2;
+    const double v4 = (yy + 3 >= 0 && yy + 3 < h) ? row(yy + 3) : v3;
+    const double v = horner(v2, -v1 + v3, 2 * (v1 - v2) + v3 - v4, -v1 + v2 - v3 + v4, dy);
+    if (U8) {
+        const double qv = v <= 0.0 ? 0.0 : (v >= 255.0 ? 255.0 : (double)(unsigned char)v);
+        out[t] = (float)(qv / 255.0);
+    } else {
+        out[t] = (float)v;
+    }
+}
+
 // ---------------------------------------------------------------- Adam over a flat buffer (A7: optim.step())
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float step_size, float sqrt_bc2, float b1, float b2, float eps) {

@@ -8,12 +8,15 @@ Same positional arguments and return tuples.  The encoder is the caller's torch 
 onward everything -- reparameterisation, pose split and KL terms (one small kernel), pose, decoder and
 log-likelihood (everything that touches B*N rows) -- goes through the HIP library (ops.py).  Differences from the
 reference, all additive: `noise=` lets a caller supply the N(0,1) draw (parity tests; data-parallel
-runs that slice one global draw), `return_logits=` also returns the pre-Sigmoid output.
-PIL-based rotation augmentation (`augment_rotation`) is host preprocessing outside the hot path
-and is not implemented here.
+runs that slice one global draw), `return_logits=` also returns the pre-Sigmoid output, `offset=` supplies the
+augmentation angles (radians) instead of the np.random draw.
+`augment_rotation` (train_galaxy.py:41-54, train_particles.py:31-43) rotates the observed images before inference
+with the device restatement of Pillow's bicubic Image.rotate (ops.rotate_augment) instead of a per-image PIL loop on
+the host; the angles come from np.random exactly as in the reference.
 """
 import math
 
+import numpy as np
 import torch
 
 from . import ops
@@ -28,16 +31,39 @@ def _encode(q_net, y2d):
     return torch.cat([z_mu, z_logstd], 1)
 
 
-def _core(script, x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior, z_scale, mask, ctf, noise, use_cuda):
+def _augment(script, y, rotate, offset):
+    """The reference's augmentation block: offset ~ U(0, 2 pi) per image from np.random (times a Bernoulli(rotate) when
+    rotate is a probability < 1), image i rotated by offset[i] -- through uint8 for galaxy images
+    (train_galaxy.py:44-54), as float32 for particles (train_particles.py:35-43)."""
+    B = y.size(0)
+    if offset is None:
+        offset = np.random.uniform(0, 2 * np.pi, size=B)
+        if rotate < 1:
+            offset = offset * np.random.binomial(1, p=rotate, size=B)
+    offset = np.asarray(offset, np.float64)
+    side = int(np.sqrt(y.size(1)))
+    return ops.rotate_augment(y, offset, side, side, quantize_u8=(script == "galaxy")), offset
+
+
+def _core(script, x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior, z_scale, mask, ctf, noise, use_cuda,
+          augment_rotation=False, offset=None):
     B = y.size(0)
     if use_cuda:
         y = y.cuda()
-    q_out = _encode(q_net, y.view(B, -1))
+    y_in = y
+    if rotate and augment_rotation:
+        y_in, offset = _augment(script, y, rotate, offset)
+    else:
+        offset = None
+    q_out = _encode(q_net, y_in.view(B, -1))
     inf_dim = q_out.size(1) // 2
     # E_q[log p(x|z)] by one reparameterised sample (train_mnist.py:36-39); the draw itself stays a torch call
     r = noise if noise is not None else torch.empty(B, inf_dim, device=x.device, dtype=q_out.dtype).normal_()
     # reparameterise + pose split + KL terms in one kernel (train_mnist.py:33-39, 42-72, 61-63, 83-85)
     theta, dx, zc, kl_b = ops.latent_head(q_out, r, rotate, translate, script == "mnist", dx_scale, z_scale, theta_prior)
+    if offset is not None and np.any(offset > 0):
+        # invert the random rotation: reconstruct the original with the offset added (train_galaxy.py:84-87)
+        theta = theta + torch.from_numpy(offset).float().to(theta.device)
 
     if hasattr(p_net, "forward_posed"):
         y_hat, logits = p_net.forward_posed(x, B, theta=theta, dx=dx, z=zc, return_logits=True)
@@ -63,22 +89,18 @@ def eval_minibatch_mnist(x, y, p_net, q_net, rotate=True, translate=True, dx_sca
 
 
 def eval_minibatch_galaxy(x, y, p_net, q_net, rotate=True, translate=True, dx_scale=0.1, theta_prior=math.pi,
-                          augment_rotation=False, z_scale=1, use_cuda=False, noise=None, return_logits=False):
-    if augment_rotation:
-        raise NotImplementedError("augment_rotation is host-side PIL preprocessing; rotate the batch before calling")
+                          augment_rotation=False, z_scale=1, use_cuda=False, noise=None, return_logits=False, offset=None):
     channels = y.size(2)
     elbo, log_p, kl, y_hat, logits = _core("galaxy", x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior,
-                                           z_scale, None, None, noise, use_cuda)
+                                           z_scale, None, None, noise, use_cuda, augment_rotation, offset)
     out = (elbo, log_p, kl, y_hat.view(y.size(0), -1, channels))
     return out + (logits,) if return_logits else out
 
 
 def eval_minibatch_particles(x, y, mask, ctf, p_net, q_net, rotate=True, translate=True, dx_scale=0.1,
                              theta_prior=math.pi, augment_rotation=False, z_scale=1, use_cuda=False, noise=None,
-                             return_logits=False):
-    if augment_rotation:
-        raise NotImplementedError("augment_rotation is host-side PIL preprocessing; rotate the batch before calling")
+                             return_logits=False, offset=None):
     elbo, log_p, kl, y_hat, logits = _core("particles", x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior,
-                                           z_scale, mask, ctf, noise, use_cuda)
+                                           z_scale, mask, ctf, noise, use_cuda, augment_rotation, offset)
     out = (elbo, log_p, kl)
     return out + (logits,) if return_logits else out

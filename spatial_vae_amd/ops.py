@@ -5,8 +5,10 @@ arithmetic of the decoder path happens in the HIP library.  There is deliberatel
 CPU tensors or a missing library raise.
 """
 import ctypes
+import math
 from collections import namedtuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -282,6 +284,49 @@ class _GaussianLoglik(torch.autograd.Function):
 
 def gaussian_loglik(y_params, target, mask=None, ctf=None):
     return _GaussianLoglik.apply(y_params, target, mask, ctf)
+
+
+def rotation_matrices(offset, rows, cols):
+    """Host part of Image.rotate for a batch: per image the six inverse-affine coefficients PIL/Image.py derives
+    from the angle (cos/sin of -radians(angle) rounded to 15 decimals about the centre (cols/2, rows/2)), and the
+    quarter-turn code of Pillow's exact fast paths (-1 = general angle).  offset: radians, as drawn by
+    train_galaxy.py:44; the reference passes 360*offset/2/pi degrees (train_galaxy.py:51)."""
+    B = len(offset)
+    mat = np.zeros((B, 6), np.float64)
+    quarter = np.full(B, -1, np.int32)
+    cx, cy = cols / 2, rows / 2
+    for i in range(B):
+        angle = (360 * float(offset[i]) / 2 / np.pi) % 360.0
+        if angle in (0.0, 180.0) or (angle in (90.0, 270.0) and rows == cols):
+            quarter[i] = int(angle // 90)
+            continue
+        a = -math.radians(angle)
+        c, s = round(math.cos(a), 15), round(math.sin(a), 15)
+        ms, mc = round(-math.sin(a), 15), round(math.cos(a), 15)
+        tx = c * (-cx) + s * (-cy) + 0.0
+        ty = ms * (-cx) + mc * (-cy) + 0.0
+        mat[i] = (c, s, tx + cx, ms, mc, ty + cy)
+    return mat, quarter
+
+
+def rotate_augment(y, offset, rows, cols, quantize_u8):
+    """Rotate image i of the batch by offset[i] radians the way the reference does with Pillow
+    (train_galaxy.py:41-54 quantize_u8=True; train_particles.py:31-43 quantize_u8=False), on the device
+    (svae_rotate_bicubic).  y: (B, rows*cols[, C]) fp32 CUDA tensor; returns a new tensor of the same shape."""
+    _require_hip(y, "y")
+    B = y.size(0)
+    yc = y.contiguous().float()
+    C = yc.numel() // (B * rows * cols)
+    if C * B * rows * cols != yc.numel() or len(offset) != B:
+        raise RuntimeError("rotate_augment: y %s does not match %d images of %dx%d" % (tuple(y.shape), len(offset), rows, cols))
+    mat, quarter = rotation_matrices(offset, rows, cols)
+    mat_d = torch.from_numpy(mat).to(y.device, non_blocking=True)
+    q_d = torch.from_numpy(quarter).to(y.device, non_blocking=True)
+    out = torch.empty_like(yc)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().svae_rotate_bicubic(yc.data_ptr(), out.data_ptr(), mat_d.data_ptr(), q_d.data_ptr(), B, rows,
+                                                  cols, C, 1 if quantize_u8 else 0, _stream(y.device)))
+    return out.view_as(y)
 
 
 class FlatAdam(torch.optim.Optimizer):

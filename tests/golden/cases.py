@@ -22,13 +22,13 @@ def _case(name, script="mnist", n=7, m=7, B=4, z_dim=2, H=20, L=2, act="tanh",
           rotate=True, translate=True, dx_scale=0.1, theta_prior=np.pi / 4,
           z_scale=1.0, n_out=1, softplus=False, resid=False, expand_coords=False,
           bilinear=False, q_hidden=24, q_layers=1, mask=False, ctf=False,
-          wscale=1.0, seed=0, store="full"):
+          wscale=1.0, seed=0, store="full", augment=False):
     return dict(name=name, script=script, n=n, m=m, B=B, z_dim=z_dim, H=H, L=L,
                 act=act, rotate=rotate, translate=translate, dx_scale=dx_scale,
                 theta_prior=float(theta_prior), z_scale=z_scale, n_out=n_out,
                 softplus=softplus, resid=resid, expand_coords=expand_coords,
                 bilinear=bilinear, q_hidden=q_hidden, q_layers=q_layers,
-                mask=mask, ctf=ctf, wscale=wscale, seed=seed, store=store)
+                mask=mask, ctf=ctf, wscale=wscale, seed=seed, store=store, augment=augment)
 
 
 # One row per variant of SURVEY.md section 8(a)/(c).  Sizes are tiny on purpose
@@ -78,6 +78,11 @@ CASES = [
           theta_prior=np.pi, seed=14),
     _case("particles_softplus_noise", script="particles", n=8, m=8, n_out=2, softplus=True,
           theta_prior=np.pi, seed=37),
+    # --augment_rotation: Pillow bicubic rotation of the observed images by np.random angles before inference
+    # (train_galaxy.py:41-54 through uint8; train_particles.py:31-43 as float32), offset added back to theta
+    _case("galaxy_augment", script="galaxy", n=8, m=8, B=5, n_out=3, L=2, z_dim=3, H=24,
+          theta_prior=np.pi, seed=50, augment=True),
+    _case("particles_augment", script="particles", n=9, m=9, B=5, theta_prior=np.pi, seed=51, augment=True),
     # BASELINE.json widths (H=500 pads to 512; 28x28 pads to 25 tiles); outputs
     # stored as strided samples + norms to keep the fixture small.
     _case("mnist_h500", n=28, m=28, B=3, H=500, q_hidden=32, seed=40, store="sampled"),
@@ -192,6 +197,8 @@ def build_inputs(case):
         out["ctf"] = f.astype(np.float32)
     else:
         out["ctf"] = None
+    # augmentation angles: what np.random.uniform(0, 2*pi, size=B) returns after np.random.seed(seed)
+    out["offset"] = np.random.RandomState(case["seed"]).uniform(0, 2 * np.pi, size=B) if case["augment"] else None
     # decoder-only entry SpatialGenerator.forward(x, z): explicit coords, z, upstream grad
     out["dec_x"] = (rs.uniform(-1.3, 1.3, size=(B, N, 2))).astype(np.float32)
     out["dec_z"] = rs.normal(size=(B, case["z_dim"])).astype(np.float32)

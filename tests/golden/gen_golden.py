@@ -102,6 +102,9 @@ def run_case(case):
         captured["q_out"] = o            # returns None: a hook's return value would replace the output
 
     hook_q = q_net.layers.register_forward_hook(_q_hook)
+    hook_in = q_net.layers.register_forward_pre_hook(lambda mod, i: captured.__setitem__("q_in", i[0].detach().clone()))
+    if case["augment"]:
+        np.random.seed(case["seed"])                 # the reference draws offset from the global numpy generator
     orig_normal = torch.Tensor.normal_
 
     def fake_normal(self, *a, **k):
@@ -115,12 +118,12 @@ def run_case(case):
         if case["script"] == "mnist":
             elbo, log_p, kl, y_hat = ref_mnist.eval_minibatch(x, y, p_net, q_net, **kw)
         elif case["script"] == "galaxy":
-            elbo, log_p, kl, y_hat = ref_galaxy.eval_minibatch(x, y, p_net, q_net, augment_rotation=False,
+            elbo, log_p, kl, y_hat = ref_galaxy.eval_minibatch(x, y, p_net, q_net, augment_rotation=case["augment"],
                                                                z_scale=case["z_scale"], **kw)
         else:
             mask = torch.from_numpy(inp["mask"]) if inp["mask"] is not None else None
             ctf = torch.from_numpy(inp["ctf"]) if inp["ctf"] is not None else None
-            elbo, log_p, kl = ref_particles.eval_minibatch(x, y, mask, ctf, p_net, q_net, augment_rotation=False,
+            elbo, log_p, kl = ref_particles.eval_minibatch(x, y, mask, ctf, p_net, q_net, augment_rotation=case["augment"],
                                                            z_scale=case["z_scale"], **kw)
             y_hat = None
     finally:
@@ -128,6 +131,9 @@ def run_case(case):
     (-elbo).backward()                               # train_mnist.py:147-148
     hook_logits.remove()
     hook_q.remove()
+    hook_in.remove()
+    if case["augment"]:
+        out["y_rot"] = captured["q_in"].numpy().reshape(inp["y"].shape)      # what Pillow made of y
 
     out["elbo"] = elbo.detach().numpy()
     out["log_p"] = log_p.detach().numpy()

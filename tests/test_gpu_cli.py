@@ -57,3 +57,14 @@ def test_train_particles_cli(tmp_path):
                                        "--q-hidden-dim", "32", "--fit-noise", "--expand-coords", "--bilinear", "--resid", "--softplus",
                                        "-a", "relu", "--progress-every", "0"], str(tmp_path))
     assert len(rows) == 3
+
+
+def test_augment_rotation_flag_runs_on_both_scripts(tmp_path):
+    """--augment_rotation / --augment-rotation (train_galaxy.py:323, train_particles.py) take the device rotation."""
+    rows = _run("train_galaxy.py", ["x", "y", "--synthetic", "64", "--num_epochs", "1", "--minibatch_size", "32", "--p_hidden_dim", "32",
+                                    "--q_hidden_dim", "32", "--augment_rotation", "--save_prefix", "ga", "--progress_every", "0"],
+                str(tmp_path))
+    assert len(rows) == 3 and all(np.isfinite([float(v) for v in r.split("\t")]).all() for r in rows[1:])
+    rows = _run("train_particles.py", ["x", "y", "--synthetic", "64", "--num-epochs", "1", "--minibatch-size", "32", "--p-hidden-dim", "32",
+                                       "--q-hidden-dim", "32", "--augment-rotation", "--progress-every", "0"], str(tmp_path))
+    assert len(rows) == 3

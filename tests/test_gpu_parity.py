@@ -50,6 +50,9 @@ def test_eval_minibatch_matches_reference(name):
     r = torch.from_numpy(inp["r"]).to(dev)
     kw = dict(rotate=case["rotate"], translate=case["translate"], dx_scale=case["dx_scale"],
               theta_prior=case["theta_prior"], noise=r, return_logits=True)
+    if case["augment"]:
+        np.random.seed(case["seed"])        # the angles come from the global numpy generator, as in the reference
+        kw["augment_rotation"] = True
     if case["script"] == "mnist":
         elbo, log_p, kl, y_hat, logits = E.eval_minibatch_mnist(x, y, p_net, q_net, **kw)
     elif case["script"] == "galaxy":

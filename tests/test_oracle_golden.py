@@ -20,7 +20,8 @@ def test_elbo_minibatch_matches_reference(name):
     spec = O.DecoderSpec.from_case(case)
     res = O.elbo_minibatch(case["script"], spec, inp["p_state"], inp["x_coord"], inp["y"], gold["q_out"], inp["r"],
                            rotate=case["rotate"], translate=case["translate"], dx_scale=case["dx_scale"],
-                           theta_prior=case["theta_prior"], z_scale=case["z_scale"], mask=inp["mask"], ctf=inp["ctf"])
+                           theta_prior=case["theta_prior"], z_scale=case["z_scale"], mask=inp["mask"], ctf=inp["ctf"],
+                           theta_offset=inp["offset"])
     assert abs(float(res["elbo"]) - float(gold["elbo"])) <= TOL * abs(float(gold["elbo"]))
     assert abs(float(res["log_p"]) - float(gold["log_p"])) <= TOL * abs(float(gold["log_p"]))
     assert abs(float(res["kl"]) - float(gold["kl"])) <= TOL * max(abs(float(gold["kl"])), 1.0)

@@ -8,14 +8,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_write -- python3 $R/tools/kbench.py --iters 2 > $R/gpurun_out/${TAG}_write.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $R/gpurun_out/${TAG}_sq -- python3 $R/tools/kbench.py --iters 2 > $R/gpurun_out/${TAG}_sq.log 2>&1
 python3 $R/tools/pmc_summary.py $R/gpurun_out/${TAG}_sq
-python3 - <<PY
-import csv, glob, collections
-for kind in ("fetch", "write"):
-    f = glob.glob("$R/gpurun_out/${TAG}_%s/*/*_counter_collection.csv" % kind)[0]
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        if "svae" in k:
-            print("%-6s %-62s avg %.1f (counter units, KB) over %d dispatches" % (kind, k, sum(v) / len(v), len(v)))
-PY
+python3 $R/tools/traffic_json.py $R/gpurun_out/${TAG}_fetch $R/gpurun_out/${TAG}_write $R/gpurun_out/${TAG}_traffic.json

@@ -45,8 +45,6 @@ def galaxy_arguments(argv=None):
 
 
 def build(args, device):
-    if args.augment_rotation:
-        raise SystemExit("--augment_rotation is PIL preprocessing on the host and is not part of this build")
     if args.synthetic > 0:
         tr = cli.synthetic_images("galaxy", args.synthetic, 32, 32, 3, 0)
         va = cli.synthetic_images("galaxy", max(args.synthetic // 4, 1), 32, 32, 3, 1)
@@ -77,7 +75,7 @@ def build(args, device):
         p_net = models.SpatialGenerator(args.z_dim, args.p_hidden_dim, n_out=channels, num_layers=args.p_num_layers, activation=act)
     q_net = models.InferenceNetwork(n * m * channels, inf_dim, args.q_hidden_dim, num_layers=args.q_num_layers, activation=act)
     return dict(y_train=y_train, y_test=y_val, n=n, m=m, p_net=p_net, q_net=q_net, rotate=rotate, translate=translate,
-                table=["Epoch", "ELBO", "BCE loss", "KL"])
+                augment=args.augment_rotation, table=["Epoch", "ELBO", "BCE loss", "KL"])
 
 
 if __name__ == "__main__":

@@ -59,8 +59,6 @@ def load_images(path):
 
 
 def build(args, device):
-    if args.augment_rotation:
-        raise SystemExit("--augment-rotation is PIL preprocessing on the host and is not part of this build")
     if args.synthetic > 0:
         tr = cli.synthetic_images("particles", args.synthetic, 40, 40, 1, 0)
         te = cli.synthetic_images("particles", max(args.synthetic // 4, 1), 40, 40, 1, 1)
@@ -109,7 +107,8 @@ def build(args, device):
     q_net = models.InferenceNetwork(n * m, inf_dim, args.q_hidden_dim, num_layers=args.q_num_layers, activation=act,
                                     resid=args.resid)
     return dict(y_train=y_train, y_test=y_test, ctf_train=ctf_train, ctf_test=ctf_test, mask=mask, n=n, m=m, p_net=p_net,
-                q_net=q_net, rotate=rotate, translate=translate, table=["Epoch", "Split", "ELBO", "Error", "KL"])
+                q_net=q_net, rotate=rotate, translate=translate, augment=args.augment_rotation,
+                table=["Epoch", "Split", "ELBO", "Error", "KL"])
 
 
 if __name__ == "__main__":
