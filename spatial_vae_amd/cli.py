@@ -7,7 +7,7 @@ declare their flag surfaces (which differ: underscores for mnist/galaxy, hyphens
 flag names and defaults, the step order (loss = -elbo; backward; step; zero_grad), the running-mean metric
 arithmetic, the stdout tables, train.txt / val.txt / command.txt / models.txt, and the whole-module
 `.sav` checkpoints with the reference's file names.  Dropped (out of scope): the
-interactive "clear outputs?" prompt (the run directory is created, never wiped), PNG/SVG dumps, the zip
+interactive "clear outputs?" prompt (the run directory is created, never wiped), the loss-curve SVG, the zip
 archive, dataset download and MRC input (raises).  `--augment_rotation` runs on the device
 (ops.rotate_augment, bit-identical to the reference's per-image Pillow loop).  Added: `--synthetic N`
 (train on N synthetic images when no data files exist), data-parallel execution under torchrun, and
@@ -81,6 +81,48 @@ def make_run_dir(prefix, args):
     return out, trained
 
 
+def save_label(args):
+    """src/misc_tools.py:15-28: '<prefix>_' + z<z_dim>pnl<p_num_layers>qnl<q_num_layers>nl<num_layers>ep<num_epochs> in
+    the order the flags were declared."""
+    names = {"z_dim": "z", "p_num_layers": "pnl", "q_num_layers": "qnl", "num_layers": "nl", "num_epochs": "ep"}
+    label = args.save_prefix + "_"
+    for k, v in vars(args).items():
+        if k in names:
+            label += names[k] + str(v)
+    return label
+
+
+def image_grid(images, nrow, padding=3, pad_value=0.5):
+    """torchvision.utils.make_grid + the uint8 conversion of save_image (torchvision 0.8.2 is what the reference pins;
+    it is not installed here, so this follows its published algorithm -- parity unpinned): images (B, C, h, w) in [0, 1]
+    -> (H, W, 3) uint8.  Single-channel batches are replicated to RGB; cells are h+padding x w+padding on a
+    pad_value canvas; value*255 + 0.5, clamped, truncated."""
+    t = np.asarray(images, np.float32)
+    if t.shape[1] == 1:
+        t = np.repeat(t, 3, axis=1)
+    B, C, h, w = t.shape
+    if B == 1:
+        grid = t[0]
+    else:
+        xmaps = min(nrow, B)
+        ymaps = int(math.ceil(float(B) / xmaps))
+        H, W = h + padding, w + padding
+        grid = np.full((C, H * ymaps + padding, W * xmaps + padding), pad_value, np.float32)
+        for k in range(B):
+            r, c = divmod(k, xmaps)
+            grid[:, r * H + padding:r * H + padding + h, c * W + padding:c * W + padding + w] = t[k]
+    arr = np.clip(grid * np.float32(255) + np.float32(0.5), 0, 255).astype(np.uint8)
+    return np.transpose(arr, (1, 2, 0))
+
+
+def export_batch_as_image(data, output, image_dims):
+    """src/misc_tools.py:30-39: a (B, N[, C]) batch as one PNG, int(sqrt(B)) images per row."""
+    from PIL import Image
+    B = data.size(0)
+    images = data.detach().float().reshape(B, image_dims[0], image_dims[1], -1).permute(0, 3, 1, 2).cpu().numpy()
+    Image.fromarray(image_grid(images, int(B ** 0.5))).save(output)
+
+
 def save_models(path_prefix, epoch_str, p_net, q_net, device):
     """torch.save(<whole module>) under the reference's names (src/misc_tools.py:88-104)."""
     for tag, net in (("generator", p_net), ("inference", q_net)):
@@ -120,6 +162,8 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
                 call.update(kw)
                 out = step.eval_minibatch(x, *args, p_net, q_net, **call)
         elbo, log_p, kl = out[0], out[1], out[2]
+        if it == 0 and extra.get("dump") and rank == 0:            # first batch of a save-interval epoch (train_mnist.py:214-224)
+            extra["dump"](y, out[3] if len(out) > 3 else None)
         vals = torch.stack([elbo.detach(), -log_p.detach(), kl.detach()]) * ((hi - lo) / gb)
         if world > 1:
             torch.distributed.all_reduce(vals)
@@ -173,6 +217,9 @@ def train_main(script, args, build):
         print("\t".join(header), file=out)
     train_lines, val_lines = ["\t".join(header)], ["\t".join(header)]
     z_delay = getattr(args, "z_delay", 0)
+    label = save_label(args) if out_dir else None
+    if out_dir:                                                      # MiscTools.sample_images: the first validation batch
+        export_batch_as_image(te["y"][:bs], "{}/images/_sample_{}.png".format(out_dir, label), [cfg["n"], cfg["m"]])
     for epoch in range(num_epochs):
         kw = {}
         if script != "mnist":
@@ -185,7 +232,11 @@ def train_main(script, args, build):
         ntest = te["y"].size(0)
         order = torch.arange(ntest)
         tb = [order[i:i + bs].to(device) for i in range(0, ntest, bs)]
-        ev = run_epoch(script, step, x, tb, False, ntest, epoch, num_epochs, rank, world, 0, dict(data=te, mask=mask, kw=kw))
+        dump = None
+        if out_dir and script != "particles" and (epoch + 1) % args.save_interval == 0:
+            dump = _image_dumper(script, step, x, cfg, out_dir, str(epoch + 1).zfill(digits), label, kw, args.z_dim)
+        ev = run_epoch(script, step, x, tb, False, ntest, epoch, num_epochs, rank, world, 0,
+                       dict(data=te, mask=mask, kw=kw, dump=dump))
         if rank == 0:
             if script == "particles":
                 print("\t".join([str(epoch + 1), "train", str(e), str(g), str(k)]), file=out)
@@ -210,6 +261,29 @@ def train_main(script, args, build):
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0
+
+
+def _image_dumper(script, step, x, cfg, out_dir, epoch_str, label, kw, z_dim):
+    """The PNG dumps of eval_model (train_mnist.py:214-224, train_galaxy.py:275-292): <epoch>_dis_ = decoded from the
+    content latents on the unposed grid, <epoch>_ = the posed reconstruction y_hat of the same batch, galaxy also
+    <epoch>_rnd_ = decoded prior samples."""
+    dims = [cfg["n"], cfg["m"]]
+    p_net, q_net = step.p_net, step.q_net
+
+    def dump(y, y_hat):
+        base = "{}/images/{}".format(out_dir, epoch_str)
+        if script == "mnist":
+            dis = E.minibatch_for_display(x, y, p_net, q_net, rotate=cfg["rotate"], translate=cfg["translate"])
+        else:
+            zs = kw.get("z_scale", 1)
+            dis = E.minibatch_for_display_galaxy(x, y, q_net, p_net, rotate=cfg["rotate"], translate=cfg["translate"], z_scale=zs)
+            rnd = E.random_minibatch_generator(x, y, p_net, z_dim, z_scale=zs)
+            export_batch_as_image(rnd, "{}_rnd_{}.png".format(base, label), dims)
+        export_batch_as_image(dis, "{}_dis_{}.png".format(base, label), dims)
+        if y_hat is not None:
+            export_batch_as_image(y_hat, "{}_{}.png".format(base, label), dims)
+
+    return dump
 
 
 def synthetic_images(kind, count, n, m, channels, seed):

@@ -104,3 +104,40 @@ def eval_minibatch_particles(x, y, mask, ctf, p_net, q_net, rotate=True, transla
                                            z_scale, mask, ctf, noise, use_cuda, augment_rotation, offset)
     out = (elbo, log_p, kl)
     return out + (logits,) if return_logits else out
+
+
+# ---------------------------------------------------------------- forward-only paths (image dumps of the training scripts)
+def _decode_unposed(x, y, p_net, q_net, rotate, translate, z_scale, use_cuda, noise):
+    B = y.size(0)
+    if use_cuda:
+        y = y.cuda()
+    q_out = _encode(q_net, y.view(B, -1))
+    inf_dim = q_out.size(1) // 2
+    r = noise if noise is not None else torch.empty(B, inf_dim, device=x.device, dtype=q_out.dtype).normal_()
+    # sample z, then drop the rotation and translation slots: the image is drawn on the UNposed grid
+    _, _, zc, _ = ops.latent_head(q_out, r, rotate, translate, False, 1.0, z_scale, math.pi)
+    if hasattr(p_net, "forward_posed"):
+        return p_net.forward_posed(x, B, z=zc)
+    return p_net(x, zc)
+
+
+@torch.no_grad()
+def minibatch_for_display(x, y, p_net, q_net, rotate=True, translate=True, z_scale=1, use_cuda=False, noise=None):
+    """train_mnist.py:93-124: reconstruct from the content latents only (pose removed) -> (B, N)."""
+    return _decode_unposed(x, y, p_net, q_net, rotate, translate, z_scale, use_cuda, noise).view(y.size(0), -1)
+
+
+@torch.no_grad()
+def minibatch_for_display_galaxy(x, y, q_net, p_net, rotate=True, translate=True, z_scale=1, use_cuda=False, noise=None):
+    """train_galaxy.py:131-163 (note the reference's argument order: q_net before p_net) -> (B, N, C)."""
+    return _decode_unposed(x, y, p_net, q_net, rotate, translate, z_scale, use_cuda, noise).view(y.size(0), -1, y.size(2))
+
+
+@torch.no_grad()
+def random_minibatch_generator(x, y, p_net, z_dim, z_scale=1, use_cuda=False, noise=None):
+    """train_galaxy.py:166-183: decode z ~ N(0, 1) * z_scale on the unposed grid -> (B, N, C)."""
+    B = y.size(0)
+    z = noise if noise is not None else torch.empty(B, z_dim, device=x.device, dtype=torch.float32).normal_()
+    z = z * z_scale
+    out = p_net.forward_posed(x, B, z=z) if hasattr(p_net, "forward_posed") else p_net(x, z)
+    return out.view(B, -1, y.size(2))

@@ -92,6 +92,9 @@ CASES = [
 
 CASES_BY_NAME = {c["name"]: c for c in CASES}
 
+# cases whose fixture also holds the forward-only display outputs (minibatch_for_display, random_minibatch_generator)
+DISPLAY_CASES = ("mnist_rt", "mnist_none", "mnist_z0", "galaxy_rgb", "galaxy_rgb_relu")
+
 
 def inf_dim(case):
     return case["z_dim"] + (1 if case["rotate"] else 0) + (2 if case["translate"] else 0)

@@ -108,8 +108,8 @@ def run_case(case):
     orig_normal = torch.Tensor.normal_
 
     def fake_normal(self, *a, **k):
-        assert tuple(self.shape) == tuple(r.shape)
-        return self.copy_(r)
+        assert self.shape[0] == r.shape[0] and self.shape[1] <= r.shape[1]
+        return self.copy_(r[:, :self.shape[1]])
 
     torch.Tensor.normal_ = fake_normal
     try:
@@ -157,6 +157,23 @@ def run_case(case):
         put_grad("gp.", k, p.grad)
     for k, p in q_net.named_parameters():
         put_grad("gq.", k, p.grad)
+
+    # --- forward-only display paths (train_mnist.py:93-124; train_galaxy.py:131-183) ---------------
+    if case["name"] in C.DISPLAY_CASES:
+        torch.Tensor.normal_ = fake_normal
+        try:
+            with torch.no_grad():
+                if case["script"] == "mnist":
+                    out["display.y_hat"] = ref_mnist.minibatch_for_display(
+                        x, y, p_net, q_net, rotate=case["rotate"], translate=case["translate"], use_cuda=False).numpy()
+                else:
+                    out["display.y_hat"] = ref_galaxy.minibatch_for_display(
+                        x, y, q_net, p_net, rotate=case["rotate"], translate=case["translate"], z_scale=case["z_scale"],
+                        use_cuda=False).numpy()
+                    out["random.y_hat"] = ref_galaxy.random_minibatch_generator(
+                        x, y, p_net, case["z_dim"], z_scale=case["z_scale"], use_cuda=False).numpy()
+        finally:
+            torch.Tensor.normal_ = orig_normal
 
     # --- decoder-only entry -------------------------------------------------
     p_net.zero_grad()

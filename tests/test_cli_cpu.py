@@ -86,3 +86,24 @@ def test_ctf_filter_matches_reference_fixture():
         got = C.ctf_filter(params, n, m, scale=s)
         assert got.shape == gold[key].shape
         assert np.abs(got - gold[key]).max() <= 1e-7 * np.abs(gold[key]).max()
+
+
+def test_image_grid_layout_and_label():
+    """make_grid/save_image restatement (src/misc_tools.py:30-39 -> torchvision.utils.save_image(nrow=rows, padding=3,
+    pad_value=0.5)) and MiscTools.save_label (src/misc_tools.py:15-28)."""
+    import argparse
+    from spatial_vae_amd import cli
+    imgs = np.zeros((5, 1, 4, 6), np.float32)
+    for k in range(5):
+        imgs[k] = (k + 1) / 10.0
+    g = cli.image_grid(imgs, nrow=2)
+    assert g.shape == (3 * 7 + 3, 2 * 9 + 3, 3) and g.dtype == np.uint8          # 3 rows x 2 columns of (4+3) x (6+3) cells
+    assert (g[:3] == 128).all() and (g[:, :3] == 128).all()                      # 0.5*255+0.5 -> 128 padding
+    assert (g[3:7, 3:9] == int(0.1 * 255 + 0.5)).all()                           # image 0
+    assert (g[3:7, 12:18] == int(np.float32(0.2) * np.float32(255) + np.float32(0.5))).all()   # image 1, same row
+    assert (g[10:14, 3:9] == int(np.float32(0.3) * np.float32(255) + np.float32(0.5))).all()   # image 2, next row
+    assert (g[17:21, 12:18] == 128).all()                                         # the sixth cell stays blank
+    one = cli.image_grid(imgs[:1], nrow=1)
+    assert one.shape == (4, 6, 3)                                                 # a single image is not padded
+    ns = argparse.Namespace(z_dim=2, p_hidden_dim=5, p_num_layers=3, q_num_layers=1, save_prefix="run", num_epochs=7)
+    assert cli.save_label(ns) == "run_z2pnl3qnl1ep7"

@@ -21,7 +21,7 @@ def _run(script, args, cwd):
 
 def test_train_mnist_cli(tmp_path):
     rows = _run("train_mnist.py", ["--synthetic", "300", "--num_epochs", "2", "--minibatch_size", "64", "--p_hidden_dim", "64",
-                                   "--q_hidden_dim", "32", "--save_prefix", "t", "--progress_every", "0"], str(tmp_path))
+                                   "--q_hidden_dim", "32", "--save_prefix", "t", "--progress_every", "0", "--save_interval", "2"], str(tmp_path))
     assert rows[0].split("\t") == ["Epoch", "ELBO", "BCE loss", "KL"]
     assert len(rows) == 1 + 2 * 2                                     # train + val line per epoch
     vals = [[float(x) for x in r.split("\t")] for r in rows[1:]]
@@ -30,6 +30,8 @@ def test_train_mnist_cli(tmp_path):
     out = tmp_path / "outputs_t"
     for f in ("train.txt", "val.txt", "command.txt", "models.txt", "trained/t_generator_epoch2.sav", "trained/t_inference_epoch2.sav"):
         assert (out / f).exists(), f
+    imgs = sorted(f.name for f in (out / "images").iterdir())
+    assert imgs == ["2_dis_t_z2nl2ep2.png", "2_t_z2nl2ep2.png", "_sample_t_z2nl2ep2.png"], imgs
     p = torch.load(out / "trained" / "t_generator_epoch2.sav", weights_only=False)       # a file this test just wrote
     assert type(p).__name__ == "SpatialGenerator" and "coord_linear.weight" in p.state_dict()
 

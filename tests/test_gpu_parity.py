@@ -161,3 +161,29 @@ def test_train_step_updates_match_plain_torch_adam():
     for (k, a), (_, b) in zip(list(p1.named_parameters()) + list(q1.named_parameters()),
                               list(p2.named_parameters()) + list(q2.named_parameters())):
         assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 2e-5, k
+
+
+@pytest.mark.parametrize("name", C.DISPLAY_CASES)
+def test_display_paths_match_reference(name):
+    """Forward-only entries behind the scripts' image dumps: minibatch_for_display (train_mnist.py:93-124,
+    train_galaxy.py:131-163) and random_minibatch_generator (train_galaxy.py:166-183)."""
+    from spatial_vae_amd import elbo as E
+    case = C.CASES_BY_NAME[name]
+    inp = C.build_inputs(case)
+    gold = load_golden(name)
+    dev = torch.device("cuda:0")
+    p_net, q_net = _nets(case, inp, dev)
+    x = torch.from_numpy(inp["x_coord"]).to(dev)
+    y = torch.from_numpy(inp["y"]).to(dev)
+    r = torch.from_numpy(inp["r"]).to(dev)
+    if case["script"] == "mnist":
+        got = E.minibatch_for_display(x, y, p_net, q_net, rotate=case["rotate"], translate=case["translate"], noise=r)
+    else:
+        got = E.minibatch_for_display_galaxy(x, y, q_net, p_net, rotate=case["rotate"], translate=case["translate"],
+                                             z_scale=case["z_scale"], noise=r)
+        rnd = E.random_minibatch_generator(x, y, p_net, case["z_dim"], z_scale=case["z_scale"],
+                                           noise=r[:, :case["z_dim"]].contiguous())
+        assert rnd.shape == gold["random.y_hat"].shape
+        assert rel_err(rnd.cpu().numpy(), gold["random.y_hat"]) < TOL
+    assert got.shape == gold["display.y_hat"].shape
+    assert rel_err(got.cpu().numpy(), gold["display.y_hat"]) < TOL
