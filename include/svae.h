@@ -223,6 +223,17 @@ int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, cons
                         int32_t cols, int32_t C, int32_t quantize_u8, svae_stream_t stream);
 
 /*
+ * Real-space CTF filter bank, one (n, m) filter per particle: the reference's ctf_filter (spatial_vae/ctf.py:33-56 --
+ * closed-form CTF of ctf.py:7-24 on the np.fft.fftfreq grid divided by apix*scale, ifft2, fftshift, real part, negated),
+ * which it evaluates per particle with numpy on the host inside the DataLoader path (train_particles.py:420-426).
+ *   params   (count, 8) doubles on the device, columns as in ctf.py:29: defocus [um], cs [mm], voltage [kV], apix [A],
+ *            bfactor, ampcont [%], dfdiff (unused by the reference), dfang [deg].
+ *   filters  (count, n, m) fp32 out -- the `ctf` operand of svae_gaussian_loglik.
+ * Arithmetic is in doubles like numpy's; the result agrees with the reference to fp32 rounding.
+ */
+int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, svae_stream_t stream);
+
+/*
  * Optional per-kernel timing (bench.py's roofline figure).  While enabled (on = 1: only the three MFMA
  * GEMM kernels, on = 2: every kernel, 0 = off), kernel launches of
  * this library are bracketed by two HIP events recorded on the launch stream; svae_profile_read

@@ -87,6 +87,8 @@ def lib():
                                  ctypes.c_float, ctypes.c_int64, vp]
     L.svae_rotate_bicubic.restype = ctypes.c_int
     L.svae_rotate_bicubic.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.svae_ctf_filter.restype = ctypes.c_int
+    L.svae_ctf_filter.argtypes = [vp, vp, i32, i32, i32, ctypes.c_double, vp]
     L.svae_profile_enable.restype = ctypes.c_int
     L.svae_profile_enable.argtypes = [ctypes.c_int]
     L.svae_profile_read.restype = ctypes.c_int

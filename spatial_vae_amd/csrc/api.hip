@@ -656,6 +656,20 @@ int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, cons
     return launch_status("svae_rotate_bicubic");
 }
 
+int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, svae_stream_t stream) {
+    if (!params || !filters || count < 1 || n < 1 || m < 1) return fail(SVAE_E_INVALID, "svae_ctf_filter: bad arguments");
+    const size_t lds = ((size_t)n * m * 3 + 2 * ((size_t)n + m)) * sizeof(double);
+    if (lds > 160 * 1024) return fail(SVAE_E_INVALID, "svae_ctf_filter: %d x %d filters do not fit the LDS (max ~80 x 80)", n, m);
+    if (!(scale > 0.0)) return fail(SVAE_E_INVALID, "svae_ctf_filter: scale must be positive");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return fail(SVAE_E_LAUNCH, "svae_ctf_filter: cannot reserve %zu bytes of LDS", lds);
+    Scope prof(K_AUGMENT, st);
+    hipLaunchKernelGGL(ctf_filter_kernel, dim3(count), dim3(256), lds, st, params, filters, n, m, scale);
+    return launch_status("svae_ctf_filter");
+}
+
 int svae_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_level = on < 0 ? 0 : (on > 2 ? 2 : on);

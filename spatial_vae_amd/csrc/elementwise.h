@@ -717,6 +717,79 @@ __global__ void rotate_bicubic_kernel(const float* __restrict__ y, float* __rest
     }
 }
 
+// ---------------------------------------------------------------- CTF filter bank (spatial_vae/ctf.py:7-56)
+// One workgroup per particle: evaluate the closed-form 2-D CTF on the FFT frequency grid (n x m), bring it to real space
+// with a separable inverse DFT (rows, then columns; doubles throughout, the sizes are ~39 x 39), fftshift, negate, store
+// as float.  params row = [defocus um, cs mm, voltage kV, apix A, bfactor, ampcont %, dfdiff, dfang deg]
+// (ctf.py:29); as in the reference dfdiff is unused: both defoci are defocus*10000 (ctf.py:47-48).
+// LDS: c (n*m doubles) | T (n*m double2) | twiddles of length m and n (double2 each).
+__global__ void __launch_bounds__(256) ctf_filter_kernel(const double* __restrict__ params, float* __restrict__ out, int n, int m,
+                                                          double scale) {
+#pragma clang fp contract(off)
+    extern __shared__ double lds_ctf[];
+    double* c = lds_ctf;
+    double2* T = reinterpret_cast<double2*>(c + (long)n * m);
+    double2* wm = T + (long)n * m;
+    double2* wn = wm + m;
+    const double* p = params + (long)blockIdx.x * 8;
+    const double apix = p[3] * scale;
+    const double dfu = p[0] * 10000.0, dfv = p[0] * 10000.0;
+    const double dfang = 2.0 * M_PI * p[7] / 360.0;
+    const double volt = p[2] * 1000.0, cs = p[1] * 1e7, w = p[5] / 100.0, bfactor = p[4];
+    const double lam = 12.2639 / sqrt(volt + 0.97845e-6 * volt * volt);
+    const double amp = sqrt(1.0 - w * w);
+    for (int k = threadIdx.x; k < m; k += 256) {
+        double sn, cn;
+        sincospi(2.0 * k / m, &sn, &cn);
+        wm[k] = make_double2(cn, sn);
+    }
+    for (int k = threadIdx.x; k < n; k += 256) {
+        double sn, cn;
+        sincospi(2.0 * k / n, &sn, &cn);
+        wn[k] = make_double2(cn, sn);
+    }
+    for (int e = threadIdx.x; e < n * m; e += 256) {
+        const int a = e / m, b = e - a * m;
+        // np.fft.fftfreq: 0, 1, ..., (len-1)/2, -(len/2), ..., -1, all over len; then / apix
+        const double fx = (double)(a <= (n - 1) / 2 ? a : a - n) / n / apix;   // ctf.py: x = first (row) frequency
+        const double fy = (double)(b <= (m - 1) / 2 ? b : b - m) / m / apix;
+        const double s2 = fx * fx + fy * fy;
+        const double df = 0.5 * (dfu + dfv + (dfu - dfv) * cos(2.0 * (atan2(fy, fx) - dfang)));
+        const double gamma = 2.0 * M_PI * (-0.5 * df * lam * s2 + 0.25 * cs * lam * lam * lam * s2 * s2);
+        c[e] = (amp * sin(gamma) - w * cos(gamma)) * exp(-bfactor / 4.0 * s2);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * m; e += 256) {  // T[a][v] = sum_b c[a][b] e^{+2 pi i b v / m}
+        const int a = e / m, v = e - a * m;
+        double re = 0.0, im = 0.0;
+        int k = 0;
+        for (int b = 0; b < m; ++b) {
+            const double cv = c[a * m + b];
+            re += cv * wm[k].x;
+            im += cv * wm[k].y;
+            k += v;
+            if (k >= m) k -= m;
+        }
+        T[e] = make_double2(re, im);
+    }
+    __syncthreads();
+    const double inv = 1.0 / ((double)n * m);
+    float* o = out + (long)blockIdx.x * n * m;
+    for (int e = threadIdx.x; e < n * m; e += 256) {  // out[i][j] = -Re X[(i + (n+1)/2) % n][(j + (m+1)/2) % m]
+        const int i = e / m, j = e - i * m;
+        const int u = (i + (n + 1) / 2) % n, v = (j + (m + 1) / 2) % m;
+        double re = 0.0;
+        int k = 0;
+        for (int a = 0; a < n; ++a) {
+            const double2 t = T[a * m + v];
+            re += t.x * wn[k].x - t.y * wn[k].y;
+            k += u;
+            if (k >= n) k -= n;
+        }
+        o[e] = (float)(-(re * inv));
+    }
+}
+
 // ---------------------------------------------------------------- Adam over a flat buffer (A7: optim.step())
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, float step_size, float sqrt_bc2, float b1, float b2, float eps) {

@@ -1,8 +1,9 @@
-"""CTF filter bank on the host -- the one-off preprocessing of /root/reference/spatial_vae/ctf.py:7-56
-(parse the 8-column parameter table, evaluate the closed-form 2-D CTF on the FFT frequency grid, bring it
-to real space with ifft2 + fftshift, negate).  Filter GENERATION is outside the hot path (SURVEY.md section
-2, row 9); filter APPLICATION is svae_gaussian_loglik's job.  numpy only (the reference uses pandas just to
-read the whitespace table)."""
+"""CTF parameter tables and the host form of the filter bank -- /root/reference/spatial_vae/ctf.py:7-56 (parse the
+8-column parameter table, evaluate the closed-form 2-D CTF on the FFT frequency grid, bring it to real space with
+ifft2 + fftshift, negate).  The training script builds its filters on the device (ops.ctf_filter ->
+svae_ctf_filter); `ctf_filter` below is the same computation with numpy for hosts without a GPU (table
+inspection, tests).  Filter APPLICATION is svae_gaussian_loglik's job.  numpy only (the reference uses pandas
+just to read the whitespace table)."""
 import numpy as np
 
 COLUMNS = ("defocus", "cs", "voltage", "apix", "bfactor", "ampcont", "dfdiff", "dfang")
@@ -14,6 +15,11 @@ def parse_ctf(path):
     if tab.shape[1] != len(COLUMNS):
         raise ValueError("expected %d CTF columns, got %d" % (len(COLUMNS), tab.shape[1]))
     return {name: tab[:, i] for i, name in enumerate(COLUMNS)}
+
+
+def ctf_table(params):
+    """Column dict -> (P, 8) float64 table in COLUMNS order (the `params` operand of svae_ctf_filter)."""
+    return np.stack([np.asarray(params[name], np.float64) for name in COLUMNS], 1)
 
 
 def ctf_2d(freqs, dfu, dfv, dfang, volt_kv, cs_mm, w, bfactor=None):

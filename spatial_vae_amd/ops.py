@@ -329,6 +329,21 @@ def rotate_augment(y, offset, rows, cols, quantize_u8):
     return out.view_as(y)
 
 
+def ctf_filter(table, n, m, scale=1.0, device=None):
+    """(P, n, m) real-space CTF filters on the device from the (P, 8) parameter table of spatial_vae/ctf.py:26-30
+    (svae_ctf_filter; the reference builds them one particle at a time with numpy, ctf.py:33-56)."""
+    tab = torch.as_tensor(np.ascontiguousarray(table, dtype=np.float64))
+    if tab.dim() != 2 or tab.size(1) != 8:
+        raise RuntimeError("ctf_filter: expected a (P, 8) parameter table, got %s" % (tuple(tab.shape),))
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    tab = tab.to(dev)
+    _require_hip(tab, "CTF table")
+    out = torch.empty(tab.size(0), n, m, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().svae_ctf_filter(tab.data_ptr(), out.data_ptr(), tab.size(0), n, m, float(scale), _stream(dev)))
+    return out
+
+
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam's update (amsgrad off, no weight decay) for ONE flat fp32 CUDA parameter, executed by
     svae_adam_step.  Same defaults and state names (step, exp_avg, exp_avg_sq) as torch.optim.Adam."""

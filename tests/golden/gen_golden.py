@@ -223,7 +223,7 @@ def gen_ctf_fixture():
     path = os.path.join(HERE, "ctf_table.txt")
     np.savetxt(path, tab)
     out = {"table": tab}
-    for n, m, scale in ((9, 9, 1), (15, 13, 2)):
+    for n, m, scale in ((9, 9, 1), (15, 13, 2), (39, 39, 1)):
         out["filt_%dx%d_s%d" % (n, m, scale)] = ref_ctf.ctf_filter(ref_ctf.parse_ctf(path), n, m, scale=scale)
     np.savez_compressed(os.path.join(HERE, "ctf_golden.npz"), **out)
     print("ctf fixture written")

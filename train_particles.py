@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 import spatial_vae.models as models
-from spatial_vae_amd import cli, ctf as C
+from spatial_vae_amd import cli, ctf as C, ops
 
 
 def particle_arguments(argv=None):
@@ -79,9 +79,9 @@ def build(args, device):
     kn, km = (n - 1 if n % 2 == 0 else n), (m - 1 if m % 2 == 0 else m)   # train_particles.py:352-358
     ctf_train = ctf_test = None
     if args.ctf_train is not None:
-        ctf_train = torch.from_numpy(C.ctf_filter(C.parse_ctf(args.ctf_train), kn, km, scale=args.scale)).float().unsqueeze(1)
+        ctf_train = ops.ctf_filter(C.ctf_table(C.parse_ctf(args.ctf_train)), kn, km, scale=args.scale, device=device).unsqueeze(1)
     if args.ctf_test is not None:
-        ctf_test = torch.from_numpy(C.ctf_filter(C.parse_ctf(args.ctf_test), kn, km, scale=args.scale)).float().unsqueeze(1)
+        ctf_test = ops.ctf_filter(C.ctf_table(C.parse_ctf(args.ctf_test)), kn, km, scale=args.scale, device=device).unsqueeze(1)
     y_train = torch.from_numpy(np.ascontiguousarray(tr)).float().view(-1, n * m)
     y_test = torch.from_numpy(np.ascontiguousarray(te)).float().view(-1, n * m)
     mask = None
