@@ -70,3 +70,15 @@ def test_augment_rotation_flag_runs_on_both_scripts(tmp_path):
     rows = _run("train_particles.py", ["x", "y", "--synthetic", "64", "--num-epochs", "1", "--minibatch-size", "32", "--p-hidden-dim", "32",
                                        "--q-hidden-dim", "32", "--augment-rotation", "--progress-every", "0"], str(tmp_path))
     assert len(rows) == 3
+
+
+def test_train_particles_reads_mrcs_stacks(tmp_path):
+    """train_particles.py:248-256: .mrcs input (memory-mapped by spatial_vae_amd/mrc.py), --crop and --normalize."""
+    from spatial_vae_amd import mrc
+    rs = np.random.RandomState(1)
+    for name, count in (("tr.mrcs", 64), ("te.mrcs", 16)):
+        with open(tmp_path / name, "wb") as f:
+            mrc.write(f, rs.normal(size=(count, 24, 24)).astype(np.float32))
+    rows = _run("train_particles.py", ["tr.mrcs", "te.mrcs", "--num-epochs", "1", "--minibatch-size", "32", "--p-hidden-dim", "32",
+                                       "--q-hidden-dim", "32", "--crop", "20", "--normalize", "--progress-every", "0"], str(tmp_path))
+    assert len(rows) == 3 and all(np.isfinite([float(v) for v in r.split("\t")[2:]]).all() for r in rows[1:])

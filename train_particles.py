@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 import spatial_vae.models as models
-from spatial_vae_amd import cli, ctf as C, ops
+from spatial_vae_amd import cli, ctf as C, mrc, ops
 
 
 def particle_arguments(argv=None):
@@ -53,9 +53,12 @@ def particle_arguments(argv=None):
 
 
 def load_images(path):
+    """train_particles.py:248-256: an MRC/MRCS stack (memory-mapped here) or a .npy array."""
+    if path.endswith("mrc") or path.endswith("mrcs"):
+        return mrc.read(path)[0]
     if path.endswith("npy"):
-        return np.load(path)
-    raise SystemExit("only .npy particle stacks are read here (MRC input is outside this build's scope): " + path)
+        return np.load(path, mmap_mode="r")
+    raise SystemExit("particle stacks are read from .mrc/.mrcs or .npy files: " + path)
 
 
 def build(args, device):
