@@ -233,22 +233,34 @@ void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const Po
                            pl.wf[l], pl.wb[l], g.H, g.Hp);
 }
 
-template <int NT, bool DGRAD, bool RESID, bool FIRST, bool LASTD>
+template <int NT, bool DGRAD, bool RESID, bool FIRST, bool LASTD, int CF = 0>
 void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
     // weight buffers, plus the W_o table (max channels x max width) behind them for LASTD
     constexpr int kLds = DenseCfg<NT>::LDS_BYTES + (LASTD ? SVAE_MAX_OUT * 4096 * 4 : 0);
     const int lds = DenseCfg<NT>::LDS_BYTES + (LASTD ? SVAE_MAX_OUT * a.Hp * 4 : 0);
     static bool attr_set = false;  // LDS beyond 64 KiB needs the opt-in attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID, FIRST, LASTD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID, FIRST, LASTD, CF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLds < 160 * 1024 ? kLds : 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID, FIRST, LASTD>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((dense_kernel<NT, DGRAD, RESID, FIRST, LASTD, CF>), grid, dim3(256), lds, st, a);
 }
 
 template <int NT, bool DGRAD>
-void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false, bool lastd = false) {
+void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
+    if constexpr (!DGRAD && NT <= 4) {  // forward of the last hidden layer with the output layer's logits in the epilogue
+        if (cf == 1) {
+            if (a.resid) launch_dense_ntr<NT, false, true, false, false, 1>(a, grid, st);
+            else launch_dense_ntr<NT, false, false, false, false, 1>(a, grid, st);
+            return;
+        }
+        if (cf == 2) {
+            if (a.resid) launch_dense_ntr<NT, false, true, false, false, 2>(a, grid, st);
+            else launch_dense_ntr<NT, false, false, false, false, 2>(a, grid, st);
+            return;
+        }
+    }
     // The fused variants (FIRST epilogue / LASTD prologue) carry more live registers; at NT >= 8 hipcc starts to
     // re-home the in-flight registers of the asm loads (tools/check_asm_loads.py), so those instantiations do
     // not exist: dense_nt_first() caps the column tiles at 4 for them.
@@ -288,16 +300,16 @@ int dense_nt_first(int ntile) {
 }
 
 template <bool DGRAD>
-void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false) {
+void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
-    const int nt = (first || lastd) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
+    const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
     switch (nt) {
-        case 16: launch_dense_nt<16, DGRAD>(a, grid, st, first, lastd); break;
-        case 8: launch_dense_nt<8, DGRAD>(a, grid, st, first, lastd); break;
-        case 4: launch_dense_nt<4, DGRAD>(a, grid, st, first, lastd); break;
-        case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first, lastd); break;
-        default: launch_dense_nt<1, DGRAD>(a, grid, st, first, lastd); break;
+        case 16: launch_dense_nt<16, DGRAD>(a, grid, st, first, lastd, cf); break;
+        case 8: launch_dense_nt<8, DGRAD>(a, grid, st, first, lastd, cf); break;
+        case 4: launch_dense_nt<4, DGRAD>(a, grid, st, first, lastd, cf); break;
+        case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first, lastd, cf); break;
+        default: launch_dense_nt<1, DGRAD>(a, grid, st, first, lastd, cf); break;
     }
 }
 
@@ -326,10 +338,11 @@ void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, hipStream_t st) {
 template <int ACT>
 void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
     Scope prof(K_LAYER0_FWD, st);
-    const unsigned gy = (unsigned)(g.noct < 32768 ? g.noct : 32768);
-    const unsigned gz = (unsigned)((g.noct + gy - 1) / gy);
+    const long ngroups = (long)g.B * ((g.Npad / 8 + kL0Group - 1) / kL0Group);
+    const unsigned gy = (unsigned)(ngroups < 32768 ? ngroups : 32768);
+    const unsigned gz = (unsigned)((ngroups + gy - 1) / gy);
     hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(g.Hp * 2), gy, gz), dim3(256), 0, st, pa, pl.posebuf,
-                       pl.tab, a0, row_geo(g), g.noct);
+                       pl.tab, a0, row_geo(g), ngroups);
 }
 
 template <int C>
@@ -390,6 +403,11 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
         for (int l = 0; l < g.L; ++l) pl.act[l] = pl.dh[l & 1];
     }
 
+    // the output layer's logits come out of the last hidden layer's epilogue (no second pass over a_{L-1}) whenever that
+    // layer is a dense_kernel launch and C <= 2; SVAE_FUSE_LOGITS=0 keeps the separate out_fwd pass
+    static const bool fuse_env = [] { const char* e = getenv("SVAE_FUSE_LOGITS"); return !(e && e[0] == '0'); }();
+    const bool fuse_logits = fuse_env && g.L >= 2 && g.C <= 2;
+
     launch_prepare(g, pl, p, pa, z, st);
     switch (g.act) {
         case SVAE_ACT_TANH: launch_layer0_fwd<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st); break;
@@ -411,8 +429,16 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
         a.resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
         a.pose = pa; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr; a.dfpart = nullptr;
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
-        a.do_p = nullptr; a.out_w = nullptr; a.C = g.C;
-        launch_dense<false>(g, a, st);
+        a.do_p = nullptr; a.out_w = p->out_w; a.C = g.C;
+        a.lpart = pl.dfpart;  // free during the forward pass; nblk * C * Mp <= ntile * 2 * Mp floats
+        launch_dense<false>(g, a, st, false, false, (fuse_logits && l == g.L - 1) ? g.C : 0);
+    }
+    if (fuse_logits) {
+        Scope prof(K_OUT_FWD, st);
+        hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
+                           logits, row_geo(g), g.C, g.ntile / dense_nt_first(g.ntile), (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0,
+                           (long)g.Mp);
+        return launch_status("svae_decoder_forward");
     }
     switch (g.C) {
         case 1: launch_out_fwd<1>(g, pl.act[g.L - 1], p, y, logits, st); break;

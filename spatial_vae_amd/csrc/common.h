@@ -163,6 +163,24 @@ __device__ __forceinline__ float wave_sum32(float v) {  // sum over the 32 lanes
     return v;
 }
 
+// Sum over the 32 lanes of one half-wave with DPP only (no LDS crossbar traffic, unlike __shfl_xor's ds_bpermute, which
+// competes with the GEMM's ds_read_b128 stream): quad butterflies, half-mirror, mirror, then row_bcast15 folds row 0
+// into row 1 (row 2 into row 3).  The result is valid in lanes 16..31 of each half-wave ONLY.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    // old = 0 with bound_ctrl lets LLVM's DPP combiner fold the move into v_add_f32_dpp where every row is enabled
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float half_sum_dpp_hi(float v) {
+    v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+    return v;
+}
+
 // sum over a 256-thread block; result valid in every thread.  red must hold 4 floats.
 __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum32(v);

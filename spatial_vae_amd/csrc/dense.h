@@ -58,6 +58,9 @@ struct DenseArgs {
     const float* do_p;   // [C][Mp] d(loss)/d(logits), zero on pad rows
     const float* out_w;  // (C, H)
     int C;
+    // CF (forward of the LAST hidden layer, C <= 2): the epilogue also contracts its activations with W_o over this
+    // workgroup's columns -- the output layer's logits, one partial per column block, so a_{L-1} is not re-read
+    float* lpart;        // [Hp/NB][C][Mp]
 };
 
 template <int ACT, bool DGRAD>
@@ -170,9 +173,10 @@ struct DenseOcc {
     static constexpr int value = NT == 16 ? 1 : (NT == 8 || FUSED) ? 2 : SVAE_NT4_WAVES;
 };
 
-template <int NT, bool DGRAD, bool RESID, bool FIRST = false, bool LASTD = false>
+template <int NT, bool DGRAD, bool RESID, bool FIRST = false, bool LASTD = false, int CF = 0>
 __global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void dense_kernel(DenseArgs a) {
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
+    static_assert(CF == 0 || (!DGRAD && CF <= 2), "CF is a forward epilogue for at most two output channels");
     static_assert(!LASTD || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using Cfg = DenseCfg<NT>;
@@ -367,6 +371,21 @@ __global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void 
                     const float bv = DGRAD ? 0.0f : a.bias[n < a.H ? n : a.H - 1];
                     bias[t] = (n < a.H) ? bv : 0.0f;
                 }
+                constexpr int CFN = CF > 0 ? CF : 1;
+                float wo[CFN][NT], lp[CFN][16];  // CF: this lane's W_o entries and its rows' partial logits
+                if (CF > 0) {
+#pragma unroll
+                    for (int c = 0; c < CFN; ++c) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int n = nb * NB + t * 32 + nl;
+                            const float wv = a.out_w[c * a.H + (n < a.H ? n : a.H - 1)];
+                            wo[c][t] = (n < a.H) ? wv : 0.0f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) lp[c][r] = 0.0f;
+                    }
+                }
                 const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;  // (q = 0, t = 0)
                 const long qstride = (long)Hp * 8;                                  // next row octet
                 float4 xa[2][4], xr[2][4];  // aux (data gradient) and residual operands of tile t / t+1
@@ -387,6 +406,13 @@ __global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void 
                         }
                         v = dense_epilogue<ACT, DGRAD>(v, bias[t], fa[q]);
                         *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = v;
+                        if (CF > 0) {
+#pragma unroll
+                            for (int c = 0; c < CFN; ++c) {
+                                lp[c][4 * q] += v.x * wo[c][t]; lp[c][4 * q + 1] += v.y * wo[c][t];
+                                lp[c][4 * q + 2] += v.z * wo[c][t]; lp[c][4 * q + 3] += v.w * wo[c][t];
+                            }
+                        }
                     }
                 };
                 if (!FIRST) {
@@ -395,6 +421,20 @@ __global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void 
                     for (int t = 0; t < NT; ++t) {
                         if ((DGRAD || RESID) && t + 1 < NT) fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
                         finish(t, xa[t & 1], xr[t & 1]);
+                    }
+                    if (CF > 0) {  // sum over this block's columns (the 32 lanes of each half-wave); lane nl == 31 stores
+#pragma unroll
+                        for (int c = 0; c < CFN; ++c)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) lp[c][r] = half_sum_dpp_hi(lp[c][r]);
+                        if (nl == 31) {
+#pragma unroll
+                            for (int c = 0; c < CFN; ++c)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)  // rows 8q + 4h .. +3 of the tile are consecutive
+                                    *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
+                                        make_float4(lp[c][4 * q], lp[c][4 * q + 1], lp[c][4 * q + 2], lp[c][4 * q + 3]);
+                        }
                     }
                 } else {
                     // coordinates of this lane's 16 rows (row 8q + 4h + r of the tile), wave-uniform image

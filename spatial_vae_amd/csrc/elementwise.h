@@ -68,37 +68,49 @@ struct RowGeo {
 // a0[m][k] = act( sum_p feat_p(x''_m) tab[b][k][p] + tab[b][k][5] ): thread = (octet, k, half)
 // computes four consecutive rows and stores them as one 16-byte vector; the thread index IS the
 // output offset, so the 411 MB stream (BASELINE cfg 2) is written perfectly linearly.
+constexpr int kL0Group = 4;  // row octets of one image per thread: the table entry is loaded once for all of them
 template <int ACT>
 __global__ void layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ posebuf, const float* __restrict__ tab,
-                                  float* __restrict__ a0, RowGeo g, long noct) {
-    // grid: x covers the Hp*2 (feature, half) pairs of one row octet, (y, z) the octets: no 64-bit divisions
+                                  float* __restrict__ a0, RowGeo g, long ngroups) {
+    // grid: x covers the Hp*2 (feature, half) pairs of one row octet, (y, z) groups of kL0Group octets of one image
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const long o = (long)blockIdx.z * gridDim.y + blockIdx.y;
-    if (t >= g.Hp * 2 || o >= noct) return;
+    const long grp = (long)blockIdx.z * gridDim.y + blockIdx.y;
+    if (t >= g.Hp * 2 || grp >= ngroups) return;
     const int h = t & 1, k = t >> 1;
     const int oimg = g.Npad >> 3;
-    const int b = (int)(o / oimg);
-    const int i0 = ((int)(o - (long)b * oimg) << 3) + 4 * h;
+    const int gpi = (oimg + kL0Group - 1) / kL0Group;
+    const int b = (int)(grp / gpi);
+    const int o0 = (int)(grp - (long)b * gpi) * kL0Group;
     const float4 pb = posebuf[b];  // identity (1, 0, 0, 0) when the coordinates are explicit
     const float4* tp = reinterpret_cast<const float4*>(tab + ((long)b * g.Hp + k) * kSlots);
     const float4 t0 = tp[0], t1 = tp[1];
-    // the four rows' coordinates: independent loads, no branches (pad rows re-read row N-1 and are zeroed)
+    // the rows' coordinates: independent loads, no branches (pad rows re-read row N-1 and are zeroed)
     const float* cbase = pose.coords ? pose.coords + (long)b * g.N * 2 : pose.grid;
-    float2 raw[4];
+    float2 raw[kL0Group][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) raw[e] = *reinterpret_cast<const float2*>(cbase + (long)(i0 + e < g.N ? i0 + e : g.N - 1) * 2);
-    float out[4];
+    for (int j = 0; j < kL0Group; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool in = i0 + e < g.N;
-        float2 x;
-        x.x = in ? pb.x * raw[e].x - pb.y * raw[e].y + pb.z : 0.0f;
-        x.y = in ? pb.y * raw[e].x + pb.x * raw[e].y + pb.w : 0.0f;
-        float v = t1.y + x.x * t0.x + x.y * t0.y;
-        if (g.in_dim == 5) v += (x.x * x.x) * t0.z + (x.y * x.y) * t0.w + (x.x * x.y) * t1.x;
-        out[e] = act_fwd<ACT>(v);
+        for (int e = 0; e < 4; ++e) {
+            const int i = ((o0 + j) << 3) + 4 * h + e;
+            raw[j][e] = *reinterpret_cast<const float2*>(cbase + (long)(i < g.N ? i : g.N - 1) * 2);
+        }
+#pragma unroll
+    for (int j = 0; j < kL0Group; ++j) {
+        if (o0 + j >= oimg) break;
+        float out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool in = ((o0 + j) << 3) + 4 * h + e < g.N;
+            float2 x;
+            x.x = in ? pb.x * raw[j][e].x - pb.y * raw[j][e].y + pb.z : 0.0f;
+            x.y = in ? pb.y * raw[j][e].x + pb.x * raw[j][e].y + pb.w : 0.0f;
+            float v = t1.y + x.x * t0.x + x.y * t0.y;
+            if (g.in_dim == 5) v += (x.x * x.x) * t0.z + (x.y * x.y) * t0.w + (x.x * x.y) * t1.x;
+            out[e] = act_fwd<ACT>(v);
+        }
+        const long o = (long)b * oimg + o0 + j;
+        *reinterpret_cast<float4*>(a0 + (o * g.Hp * 2 + t) * 4) = make_float4(out[0], out[1], out[2], out[3]);
     }
-    *reinterpret_cast<float4*>(a0 + (o * g.Hp * 2 + t) * 4) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 // ---------------------------------------------------------------- output layer, forward (A4)
@@ -148,6 +160,25 @@ __global__ void out_fwd_kernel(const float* __restrict__ a, const float* __restr
                 }
             }
         }
+    }
+}
+
+// Output layer when the last dense_kernel already contracted a_{L-1} with W_o (CF epilogue): sum the per-column-block
+// partial logits [nblk][C][Mp], add the bias, apply Sigmoid (+softplus).  One thread per (image, pixel).
+__global__ void logits_finish_kernel(const float* __restrict__ lpart, const float* __restrict__ out_b, float* __restrict__ y,
+                                     float* __restrict__ logits, RowGeo g, int C, int nblk, int softplus, long Mp) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)g.B * g.N) return;
+    const int b = (int)(t / g.N), i = (int)(t - (long)b * g.N);
+    const long m = (long)b * g.Npad + i;
+    for (int c = 0; c < C; ++c) {
+        float lg = 0.0f;
+        for (int k = 0; k < nblk; ++k) lg += lpart[((long)k * C + c) * Mp + m];
+        lg += out_b[c];
+        float s = 1.0f / (1.0f + expf(-lg));
+        if (softplus && c == 0) s = log1pf(expf(s));
+        y[t * C + c] = s;
+        if (logits) logits[t * C + c] = lg;
     }
 }
 
