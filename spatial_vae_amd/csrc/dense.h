@@ -500,11 +500,11 @@ __global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void 
                     }
                     // d(coords) of each row: sum this block's NB features = over the tiles (done) and the 32 lanes
 #pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) {
-                        pd0[idx] = wave_sum32(pd0[idx]);
-                        pd1[idx] = wave_sum32(pd1[idx]);
+                    for (int idx = 0; idx < 16; ++idx) {  // DPP only: result in lanes 16..31 of each half-wave
+                        pd0[idx] = half_sum_dpp_hi(pd0[idx]);
+                        pd1[idx] = half_sum_dpp_hi(pd1[idx]);
                     }
-                    if (nl == 0) {
+                    if (nl == 31) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
 #pragma unroll
