@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <math.h>
 #include <mutex>
 #include <type_traits>
@@ -11,6 +12,7 @@
 #include "common.h"
 #include "dense.h"
 #include "elementwise.h"
+#include "split.h"
 
 using namespace svae;
 
@@ -58,6 +60,8 @@ struct Plan {
     float* dcoords;
     float* sgtile;  // fused first-layer backward: per-tile sums (tiles x 2 x Hp x 4)
     float* dfpart;  // fused first-layer backward: per-column-block d(coords) (ntile x Mp x 2)
+    uint4* splitA;  // fp16x3 mode: the row operand as hi/lo half fragments (Mp x Hp x 4 bytes)
+    uint4* splitW;  // fp16x3 mode: one layer's weights as hi/lo half fragments
     // split geometry
     int wg_nblk1, wg_S;
     long ob_oct_per_chunk;
@@ -65,6 +69,12 @@ struct Plan {
     int l0_oct_per_chunk, l0_chunks_per_image;
     size_t saved_bytes, ws_bytes;
 };
+
+// SVAE_GEMM=fp16x3: hidden-layer GEMMs on the f16 matrix pipe with split (hi + lo/2048) operands, see split.h
+bool split_mode() {
+    static const bool on = [] { const char* e = getenv("SVAE_GEMM"); return e && strcmp(e, "fp16x3") == 0; }();
+    return on;
+}
 
 Plan make_plan(const Geo& g, void* saved, void* ws) {
     Plan p;
@@ -122,6 +132,11 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.dcoords = cw.take<float>((size_t)g.B * g.N * 2);
     p.sgtile = cw.take<float>((size_t)g.tiles * 2 * g.Hp * 4);
     p.dfpart = cw.take<float>((size_t)g.ntile * g.Mp * 2);
+    p.splitA = p.splitW = nullptr;
+    if (split_mode()) {
+        p.splitA = cw.take<uint4>(MH / 4);
+        p.splitW = cw.take<uint4>((size_t)g.Hp * g.Hp / 4);
+    }
     p.ws_bytes = (cw.off + 255) & ~size_t(255);
     return p;
 }
@@ -299,6 +314,40 @@ int dense_nt_first(int ntile) {
     return nt;
 }
 
+template <int NT, bool RESID>
+void launch_split_fwd_c(const SplitArgs& a, dim3 grid, int cf, hipStream_t st) {
+    constexpr int lds = SplitCfg<NT>::LDS_BYTES;
+    switch (cf) {
+        case 1: hipLaunchKernelGGL((dense_split_fwd_kernel<NT, RESID, 1>), grid, dim3(256), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((dense_split_fwd_kernel<NT, RESID, 2>), grid, dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL((dense_split_fwd_kernel<NT, RESID, 0>), grid, dim3(256), lds, st, a); break;
+    }
+}
+
+// forward hidden layer in fp16x3 mode: split the weights and the row operand, then the f16-MFMA GEMM
+void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float* W, const float* bias, float* out, bool resid,
+                      int cf, const float* out_w, hipStream_t st) {
+    {
+        Scope prof(K_PREPARE, st);
+        hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W,
+                           pl.splitW, g.H, g.Hp, 0);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, in, pl.splitA,
+                           g.tiles, g.Hp);
+    }
+    Scope prof(K_DENSE_FWD, st);
+    SplitArgs a;
+    a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = bias; a.resid = in;
+    a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
+    a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
+    const int nt = dense_nt_first(g.ntile);
+    const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
+    switch (nt) {
+        case 4: resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st); break;
+        case 2: resid ? launch_split_fwd_c<2, true>(a, grid, cf, st) : launch_split_fwd_c<2, false>(a, grid, cf, st); break;
+        default: resid ? launch_split_fwd_c<1, true>(a, grid, cf, st) : launch_split_fwd_c<1, false>(a, grid, cf, st); break;
+    }
+}
+
 template <bool DGRAD>
 void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
@@ -415,7 +464,13 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
         case SVAE_ACT_RELU: launch_layer0_fwd<SVAE_ACT_RELU>(g, pl, pa, pl.act[0], st); break;
         default: launch_layer0_fwd<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st); break;
     }
+    const bool split = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID);  // bounded operands only
     for (int l = 1; l < g.L; ++l) {
+        if (split) {
+            launch_split_fwd(g, pl, pl.act[l - 1], p->hidden_w[l - 1], p->hidden_b[l - 1], pl.act[l],
+                             (g.flags & SVAE_FLAG_RESID) != 0, (fuse_logits && l == g.L - 1) ? g.C : 0, p->out_w, st);
+            continue;
+        }
         DenseArgs a;
         a.in = pl.act[l - 1];
         a.wp = pl.wf[l - 1];
