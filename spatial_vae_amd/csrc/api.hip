@@ -326,13 +326,14 @@ void launch_split_fwd_c(const SplitArgs& a, dim3 grid, int cf, hipStream_t st) {
 
 // forward hidden layer in fp16x3 mode: split the weights and the row operand, then the f16-MFMA GEMM
 void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float* W, const float* bias, float* out, bool resid,
-                      int cf, const float* out_w, hipStream_t st) {
+                      int cf, const float* out_w, bool rows_ready, hipStream_t st) {
     {
         Scope prof(K_PREPARE, st);
         hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W,
                            pl.splitW, g.H, g.Hp, 0);
-        hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, in, pl.splitA,
-                           g.tiles, g.Hp);
+        if (!rows_ready)  // deeper layers: the previous GEMM wrote fp32 only
+            hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, in,
+                               pl.splitA, g.tiles, g.Hp);
     }
     Scope prof(K_DENSE_FWD, st);
     SplitArgs a;
@@ -340,7 +341,8 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
     const int nt = dense_nt_first(g.ntile);
-    const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
+    const long groups = (g.tiles + 3) / 4;
+    const dim3 grid((unsigned)(((groups + 7) / 8) * 8 * (g.ntile / nt)));  // see the kernel: (xcd, column block, group / 8)
     switch (nt) {
         case 4: resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st); break;
         case 2: resid ? launch_split_fwd_c<2, true>(a, grid, cf, st) : launch_split_fwd_c<2, false>(a, grid, cf, st); break;
@@ -392,6 +394,13 @@ void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* 
     const unsigned gz = (unsigned)((ngroups + gy - 1) / gy);
     hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(g.Hp * 2), gy, gz), dim3(256), 0, st, pa, pl.posebuf,
                        pl.tab, a0, row_geo(g), ngroups);
+}
+
+template <int ACT>
+void launch_layer0_fwd_split(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
+    Scope prof(K_LAYER0_FWD, st);  // Hp is a multiple of 64 here (ntile even)
+    hipLaunchKernelGGL((layer0_fwd_split_kernel<ACT>), dim3((unsigned)g.tiles, (unsigned)(g.Hp / 64)), dim3(256), 0, st, pa,
+                       pl.posebuf, pl.tab, a0, pl.splitA, row_geo(g));
 }
 
 template <int C>
@@ -458,17 +467,26 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
     const bool fuse_logits = fuse_env && g.L >= 2 && g.C <= 2;
 
     launch_prepare(g, pl, p, pa, z, st);
-    switch (g.act) {
-        case SVAE_ACT_TANH: launch_layer0_fwd<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st); break;
-        case SVAE_ACT_LEAKYRELU: launch_layer0_fwd<SVAE_ACT_LEAKYRELU>(g, pl, pa, pl.act[0], st); break;
-        case SVAE_ACT_RELU: launch_layer0_fwd<SVAE_ACT_RELU>(g, pl, pa, pl.act[0], st); break;
-        default: launch_layer0_fwd<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st); break;
+    // fp16x3: bounded operands only, contraction length a multiple of 64
+    const bool split = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0;
+    static const bool l0_env = [] { const char* e = getenv("SVAE_SPLIT_L0"); return !(e && e[0] == '0'); }();
+    const bool split_l0 = l0_env && split && g.L >= 2;
+    if (split_l0) {  // a0 leaves the coordinate layer in both forms: no conversion pass before the first GEMM
+        if (g.act == SVAE_ACT_TANH) launch_layer0_fwd_split<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st);
+        else launch_layer0_fwd_split<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st);
+    } else {
+        switch (g.act) {
+            case SVAE_ACT_TANH: launch_layer0_fwd<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st); break;
+            case SVAE_ACT_LEAKYRELU: launch_layer0_fwd<SVAE_ACT_LEAKYRELU>(g, pl, pa, pl.act[0], st); break;
+            case SVAE_ACT_RELU: launch_layer0_fwd<SVAE_ACT_RELU>(g, pl, pa, pl.act[0], st); break;
+            default: launch_layer0_fwd<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st); break;
+        }
     }
-    const bool split = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID);  // bounded operands only
     for (int l = 1; l < g.L; ++l) {
         if (split) {
             launch_split_fwd(g, pl, pl.act[l - 1], p->hidden_w[l - 1], p->hidden_b[l - 1], pl.act[l],
-                             (g.flags & SVAE_FLAG_RESID) != 0, (fuse_logits && l == g.L - 1) ? g.C : 0, p->out_w, st);
+                             (g.flags & SVAE_FLAG_RESID) != 0, (fuse_logits && l == g.L - 1) ? g.C : 0, p->out_w,
+                             /*rows_ready=*/split_l0 && l == 1, st);
             continue;
         }
         DenseArgs a;

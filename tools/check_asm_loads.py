@@ -15,6 +15,17 @@ import re
 import sys
 
 REG = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+SREG = re.compile(r'\bs\[(\d+):(\d+)\]|\bs(\d+)\b')
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
 
 
 def regs(text):
@@ -35,8 +46,28 @@ def check(src, name):
     in_asm = False
     queue = []          # outstanding VMEM ops issued from asm, oldest first: set of dest regs (may be empty)
     bad = 0
+    # second check: an SGPR written by a VALU instruction (v_readfirstlane / v_readlane) needs 5 wait states before a
+    # vector-memory instruction reads it; the compiler's hazard recognizer does not see SGPR operands of inline asm
+    valu_sgpr = {}      # sgpr -> instructions issued since the VALU write
     for ln, line in enumerate(m.group(1).split('\n')):
         t = line.strip()
+        if t and not t.startswith(';') and not t.startswith('.'):
+            nops = 1
+            mm = re.match(r's_nop\s+(\d+)', t)
+            if mm:
+                nops = int(mm.group(1)) + 1
+            for k in list(valu_sgpr):
+                valu_sgpr[k] += nops
+                if valu_sgpr[k] > 8:
+                    del valu_sgpr[k]
+            if in_asm and (t.startswith('global_load') or t.startswith('global_store')):
+                stale = [r for r in sregs(t) if r in valu_sgpr and valu_sgpr[r] <= 5]
+                if stale:
+                    bad += 1
+                    print("  %s: line %d reads VALU-written s%s too early: %s" % (name[:50], ln, stale, t[:80]))
+            if t.startswith('v_readfirstlane') or t.startswith('v_readlane'):
+                for r in sregs(t.split(',')[0]):
+                    valu_sgpr[r] = 0
         if t.startswith(';;#ASMSTART'):
             in_asm = True
             continue
@@ -73,5 +104,5 @@ if __name__ == '__main__':
     s = open(sys.argv[1]).read()
     names = sys.argv[2:]
     if not names:
-        names = sorted(set(re.findall(r'^(_ZN4svae12(?:dense_kernel|wgrad_kernel)\w+):', s, re.M)))
+        names = sorted(set(re.findall(r'^(_ZN4svae\d+(?:dense_kernel|wgrad_kernel|dense_split_\w+_kernel)\w+):', s, re.M)))
     sys.exit(max(check(s, n) for n in names))
