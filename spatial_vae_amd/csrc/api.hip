@@ -62,6 +62,8 @@ struct Plan {
     float* dfpart;  // fused first-layer backward: per-column-block d(coords) (ntile x Mp x 2)
     uint4* splitA;  // fp16x3 mode: the row operand as hi/lo half fragments (Mp x Hp x 4 bytes)
     uint4* splitW;  // fp16x3 mode: one layer's weights as hi/lo half fragments
+    float* gscale;  // fp16x3 mode: {s, 1/s} power-of-two scale of the gradient entering the last hidden layer
+    unsigned* amax; // fp16x3 mode: max |d loss / d logits| as float bits
     // split geometry
     int wg_nblk1, wg_S;
     long ob_oct_per_chunk;
@@ -133,9 +135,13 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.sgtile = cw.take<float>((size_t)g.tiles * 2 * g.Hp * 4);
     p.dfpart = cw.take<float>((size_t)g.ntile * g.Mp * 2);
     p.splitA = p.splitW = nullptr;
+    p.gscale = nullptr;
+    p.amax = nullptr;
     if (split_mode()) {
         p.splitA = cw.take<uint4>(MH / 4);
         p.splitW = cw.take<uint4>((size_t)g.Hp * g.Hp / 4);
+        p.gscale = cw.take<float>(64);
+        p.amax = cw.take<unsigned>(64);
     }
     p.ws_bytes = (cw.off + 255) & ~size_t(255);
     return p;
@@ -318,10 +324,27 @@ template <int NT, bool RESID>
 void launch_split_fwd_c(const SplitArgs& a, dim3 grid, int cf, hipStream_t st) {
     constexpr int lds = SplitCfg<NT>::LDS_BYTES;
     switch (cf) {
-        case 1: hipLaunchKernelGGL((dense_split_fwd_kernel<NT, RESID, 1>), grid, dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((dense_split_fwd_kernel<NT, RESID, 2>), grid, dim3(256), lds, st, a); break;
-        default: hipLaunchKernelGGL((dense_split_fwd_kernel<NT, RESID, 0>), grid, dim3(256), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 1>), grid, dim3(256), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 2>), grid, dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 0>), grid, dim3(256), lds, st, a); break;
     }
+}
+
+template <int NT>
+void launch_split_bwd_c(const SplitArgs& a, dim3 grid, bool first, bool resid, hipStream_t st) {
+    constexpr int lds = SplitCfg<NT>::LDS_BYTES;
+    if (first) {
+        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 2, true, 0>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((dense_split_kernel<NT, 2, false, 0>), grid, dim3(256), lds, st, a);
+    } else {
+        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 1, true, 0>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((dense_split_kernel<NT, 1, false, 0>), grid, dim3(256), lds, st, a);
+    }
+}
+
+dim3 split_grid(const Geo& g, int nt) {  // see dense_split_kernel: (xcd, column block, group / 8)
+    const long groups = (g.tiles + 3) / 4;
+    return dim3((unsigned)(((groups + 7) / 8) * 8 * (g.ntile / nt)));
 }
 
 // forward hidden layer in fp16x3 mode: split the weights and the row operand, then the f16-MFMA GEMM
@@ -333,20 +356,46 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
                            pl.splitW, g.H, g.Hp, 0);
         if (!rows_ready)  // deeper layers: the previous GEMM wrote fp32 only
             hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, in,
-                               pl.splitA, g.tiles, g.Hp);
+                               pl.splitA, g.tiles, g.Hp, (const float*)nullptr);
     }
     Scope prof(K_DENSE_FWD, st);
     SplitArgs a;
     a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = bias; a.resid = in;
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
+    a.aux = nullptr; a.scale = nullptr; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr; a.N = g.N; a.Timg = g.Timg;
     const int nt = dense_nt_first(g.ntile);
-    const long groups = (g.tiles + 3) / 4;
-    const dim3 grid((unsigned)(((groups + 7) / 8) * 8 * (g.ntile / nt)));  // see the kernel: (xcd, column block, group / 8)
+    const dim3 grid = split_grid(g, nt);
     switch (nt) {
         case 4: resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st); break;
         case 2: resid ? launch_split_fwd_c<2, true>(a, grid, cf, st) : launch_split_fwd_c<2, false>(a, grid, cf, st); break;
         default: resid ? launch_split_fwd_c<1, true>(a, grid, cf, st) : launch_split_fwd_c<1, false>(a, grid, cf, st); break;
+    }
+}
+
+// data gradient of the LAST hidden layer in fp16x3 mode: dh (fp32, scaled by pl.gscale) -> split rows, W^T -> split weights
+void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const float* W, const float* aux, float* out, bool resid,
+                        bool first, const PoseArgs& pa, hipStream_t st) {
+    {
+        Scope prof(K_PREPARE, st);
+        hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W,
+                           pl.splitW, g.H, g.Hp, 1);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, dh, pl.splitA,
+                           g.tiles, g.Hp, (const float*)pl.gscale);
+    }
+    Scope prof(K_DENSE_DGRAD, st);
+    SplitArgs a;
+    a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = nullptr; a.resid = dh;
+    a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
+    a.out_w = nullptr; a.lpart = nullptr; a.Mp = g.Mp;
+    a.aux = aux; a.scale = pl.gscale; a.pose = pa; a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile;
+    a.dfpart = pl.dfpart; a.N = g.N; a.Timg = g.Timg;
+    const int nt = dense_nt_first(g.ntile);
+    const dim3 grid = split_grid(g, nt);
+    switch (nt) {
+        case 4: launch_split_bwd_c<4>(a, grid, first, resid, st); break;
+        case 2: launch_split_bwd_c<2>(a, grid, first, resid, st); break;
+        default: launch_split_bwd_c<1>(a, grid, first, resid, st); break;
     }
 }
 
@@ -539,14 +588,22 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     const int resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
 
     launch_prepare(g, pl, p, pa, z, st);
+    // fp16x3: the data gradient of the last hidden layer runs on the f16 pipe (bounded act', contraction multiple of 64)
+    const char* fuse_env0 = getenv("SVAE_FUSE_OUT");
+    const bool split_bwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0 &&
+                           g.L >= 2 && !(fuse_env0 && fuse_env0[0] == '1');
 
     // d(loss)/d(logits) in padded row space (pad rows exactly zero)
     {
         Scope prof(K_DLOGITS, st);
         if (hipMemsetAsync(pl.do_p, 0, (size_t)g.C * g.Mp * sizeof(float), st) != hipSuccess)
             return fail(SVAE_E_LAUNCH, "memset failed");
+        if (split_bwd && hipMemsetAsync(pl.amax, 0, sizeof(unsigned), st) != hipSuccess) return fail(SVAE_E_LAUNCH, "memset failed");
         hipLaunchKernelGGL(dlogits_kernel, dim3(blocks_for((long)g.B * g.N * g.C)), dim3(256), 0, st, logits, dy, dy_scale,
-                           pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
+                           pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp,
+                           split_bwd ? pl.amax : (unsigned*)nullptr);
+        if (split_bwd)
+            hipLaunchKernelGGL(split_scale_kernel, dim3(1), dim3(256), 0, st, pl.amax, p->out_w, g.C, g.H, pl.gscale);
     }
 
     // Output layer.  With at least one hidden layer and no residual, dh_{L-1} is never materialised: both
@@ -607,7 +664,10 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
         a.do_p = pl.do_p; a.out_w = p->out_w; a.C = g.C;
         fused_first = (l == 1) && g.in_dim == 2;
-        launch_dense<true>(g, a, st, fused_first, last);
+        if (split_bwd && l == g.L - 1)
+            launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa, st);
+        else
+            launch_dense<true>(g, a, st, fused_first, last);
         cur ^= 1;
     }
 

@@ -187,18 +187,27 @@ __global__ void logits_finish_kernel(const float* __restrict__ lpart, const floa
 // memset), recomputing s from the logits exactly as the forward did.
 __global__ void dlogits_kernel(const float* __restrict__ logits, const float* __restrict__ dy,
                                const float* __restrict__ dy_scale, float* __restrict__ do_p, int B, int N, int Npad,
-                               int C, int softplus, long Mp) {
+                               int C, int softplus, long Mp, unsigned* __restrict__ amax) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * N * C) return;
-    const int c = idx % C;
-    const long bi = idx / C;
-    const int i = bi % N, b = bi / N;
-    const float lg = logits[idx];
-    const float s = 1.0f / (1.0f + expf(-lg));
-    float g = dy[idx];
-    if (dy_scale) g *= dy_scale[b];
-    if (softplus && c == 0) g *= 1.0f / (1.0f + expf(-s));
-    do_p[(long)c * Mp + (long)b * Npad + i] = g * s * (1.0f - s);
+    float m = 0.0f;
+    if (idx < (long)B * N * C) {
+        const int c = idx % C;
+        const long bi = idx / C;
+        const int i = bi % N, b = bi / N;
+        const float lg = logits[idx];
+        const float s = 1.0f / (1.0f + expf(-lg));
+        float g = dy[idx];
+        if (dy_scale) g *= dy_scale[b];
+        if (softplus && c == 0) g *= 1.0f / (1.0f + expf(-s));
+        const float v = g * s * (1.0f - s);
+        do_p[(long)c * Mp + (long)b * Npad + i] = v;
+        m = fabsf(v);
+    }
+    if (amax) {  // fp16x3 mode: max |do| (non-negative floats order like their bit patterns; max is order-independent)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+    }
 }
 
 // ---------------------------------------------------------------- output layer, backward, step 2

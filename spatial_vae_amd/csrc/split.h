@@ -90,8 +90,10 @@ __global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restr
     ws[(blk + 1) * 64 + lane] = lo;
 }
 
-// fp32 octet-major plane (element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)) -> As
-__global__ void split_rows_kernel(const float* __restrict__ in, uint4* __restrict__ as, long tiles, int Hp) {
+// fp32 octet-major plane (element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)) -> As, optionally multiplied by *scale first
+// (gradients are far below the half range: a power-of-two scale brings them into it, the GEMM epilogue divides it out)
+__global__ void split_rows_kernel(const float* __restrict__ in, uint4* __restrict__ as, long tiles, int Hp,
+                                  const float* __restrict__ scale) {
     const int KC = Hp / 16;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (T, kc, lane)
     if (idx >= tiles * KC * 64) return;
@@ -101,9 +103,10 @@ __global__ void split_rows_kernel(const float* __restrict__ in, uint4* __restric
     const long m = T * 32 + (lane & 31);
     const int k0 = kc * 16 + 8 * (lane >> 5);
     const float* p = in + ((m >> 3) * Hp + k0) * 8 + (m & 7);
+    const float sc = scale ? scale[0] : 1.0f;
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = p[j * 8];
+    for (int j = 0; j < 8; ++j) x[j] = p[j * 8] * sc;
     uint4 hi, lo;
     split8(x, hi, lo);
     const long blk = (T * KC + kc) * 2;
@@ -166,6 +169,33 @@ __global__ void __launch_bounds__(256) layer0_fwd_split_kernel(PoseArgs pose, co
     }
 }
 
+// Power-of-two scale for the gradient entering the last hidden layer: |dh[m][n]| = |sum_c do[m][c] W_o[c][n]| act' is at
+// most  amax|do| * C * amax|W_o|  (act' <= 1 for tanh and sigmoid); the scale maps that bound to 2^14, inside the half
+// range with room for the GEMM's partial sums.  scale[0] = s, scale[1] = 1/s (both exact).
+__global__ void split_scale_kernel(const unsigned* __restrict__ amax_do_bits, const float* __restrict__ out_w, int C, int H,
+                                   float* __restrict__ scale) {
+    __shared__ float red[4];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < C * H; i += 256) m = fmaxf(m, fabsf(out_w[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float wmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float bound = __uint_as_float(amax_do_bits[0]) * (float)C * wmax;
+        float sc = 1.0f;
+        if (bound > 0.0f && bound < 3.0e38f) {
+            int e;
+            frexpf(16384.0f / bound, &e);  // 16384 / bound = f * 2^e, f in [0.5, 1)
+            e = e - 1 < -60 ? -60 : (e - 1 > 60 ? 60 : e - 1);
+            sc = ldexpf(1.0f, e);
+        }
+        scale[0] = sc;
+        scale[1] = 1.0f / sc;
+    }
+}
+
 struct SplitArgs {
     const uint4* as;     // row operand, split
     const uint4* ws;     // weights, split
@@ -178,6 +208,16 @@ struct SplitArgs {
     const float* out_w;
     float* lpart;
     long Mp;
+    // data gradient (MODE 1 / 2): act' of aux multiplies the result; scale[1] undoes the operand scale
+    const float* aux;    // a_{l-1}, fp32 octet-major
+    const float* scale;  // device: {s, 1/s} or null
+    // MODE 2 (into the coordinate layer): reduced on the spot, see dense_kernel FIRST
+    PoseArgs pose;
+    const float4* posebuf;
+    const float* tab;
+    float* sgtile;
+    float* dfpart;
+    int N, Timg;
 };
 
 // timing-only ablation switches (never set in the product build): 1 = every tile reads the rows of tile 0 (L2-hot row
@@ -193,9 +233,13 @@ struct SplitCfg {
     static constexpr int LDS_BYTES = 2 * BLOCKS * 1024;    // double-buffered
 };
 
-// out(32 rows x NT*32 cols per wave) = act( As * Ws + bias [+ resid] ); 4 waves (4 row tiles) share the weight chunks.
-template <int NT, bool RESID, int CF>
-__global__ __launch_bounds__(256, 2) void dense_split_fwd_kernel(SplitArgs a) {
+// MODE 0: out(32 rows x NT*32 cols per wave) = act( As * Ws + bias [+ resid] )            (forward; CF: + partial logits)
+// MODE 1: out = ((As * Ws) / s [+ resid]) * act'(aux)                                      (data gradient, stored)
+// MODE 2: the same value reduced on the spot into the coordinate layer's partial sums      (dense_kernel's FIRST)
+// 4 waves (4 row tiles) share the weight chunks.
+template <int NT, int MODE, bool RESID, int CF>
+__global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
+    static_assert(CF == 0 || MODE == 0, "CF is a forward epilogue");
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     using Cfg = SplitCfg<NT>;
     constexpr int G = kSplitG, BLOCKS = Cfg::BLOCKS;
@@ -339,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void dense_split_fwd_kernel(SplitArgs a) {
     if (!live) return;
     auto epi = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
+        if constexpr (MODE == 0) {
         constexpr int NB = NT * 32;
         constexpr int CFN = CF > 0 ? CF : 1;
         float wo[CFN][NT], lp[CFN][16], bias[NT];
@@ -395,6 +440,86 @@ __global__ __launch_bounds__(256, 2) void dense_split_fwd_kernel(SplitArgs a) {
                         *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
                             make_float4(lp[c][4 * q], lp[c][4 * q + 1], lp[c][4 * q + 2], lp[c][4 * q + 3]);
             }
+        }
+            } else {
+        constexpr int NB = NT * 32;
+        const float inv = a.scale ? a.scale[1] : 1.0f;
+        const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;
+        const long qstride = (long)Hp * 8;
+        auto value = [&](int t, int q) {  // this lane's 4 rows (8q + 4h + 0..3) of column tile t, times act'(a_{l-1})
+            const long off = off0 + q * qstride + (long)t * 32 * 8;
+            float4 v = make_float4((acc[t][4 * q] + accx[t][4 * q] * kLoInv) * inv,
+                                   (acc[t][4 * q + 1] + accx[t][4 * q + 1] * kLoInv) * inv,
+                                   (acc[t][4 * q + 2] + accx[t][4 * q + 2] * kLoInv) * inv,
+                                   (acc[t][4 * q + 3] + accx[t][4 * q + 3] * kLoInv) * inv);
+            if (RESID) {
+                const float4 fr = *reinterpret_cast<const float4*>(a.resid + off);
+                v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
+            }
+            const float4 ax = *reinterpret_cast<const float4*>(a.aux + off);
+            v.x *= act_grad<ACT>(ax.x); v.y *= act_grad<ACT>(ax.y); v.z *= act_grad<ACT>(ax.z); v.w *= act_grad<ACT>(ax.w);
+            return v;
+        };
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = value(t, q);
+        } else {
+            // coordinates of this lane's 16 rows (row 8q + 4h + r of the tile), wave-uniform image
+            const int b = (int)(tl / a.Timg);
+            const int i0 = (int)(tl % a.Timg) * 32 + 4 * h;
+            const float4 pb = a.posebuf[b];
+            const float* cbase = a.pose.coords ? a.pose.coords + (long)b * a.N * 2 : a.pose.grid;
+            float x0[16], x1[16], pd0[16], pd1[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 8 * q + r;
+                    const float2 g2 = *reinterpret_cast<const float2*>(cbase + (long)(i < a.N ? i : a.N - 1) * 2);
+                    const bool in = i < a.N;
+                    x0[4 * q + r] = in ? pb.x * g2.x - pb.y * g2.y + pb.z : 0.0f;
+                    x1[4 * q + r] = in ? pb.y * g2.x + pb.x * g2.y + pb.w : 0.0f;
+                    pd0[4 * q + r] = 0.0f;
+                    pd1[4 * q + r] = 0.0f;
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int k = nb * NB + t * 32 + nl;
+                const float2 w = *reinterpret_cast<const float2*>(a.tab + ((long)b * Hp + k) * kSlots);
+                float sv = 0.0f, g0 = 0.0f, g1 = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = value(t, q);
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sv += vv[r];
+                        g0 += vv[r] * x0[4 * q + r];
+                        g1 += vv[r] * x1[4 * q + r];
+                        pd0[4 * q + r] += vv[r] * w.x;
+                        pd1[4 * q + r] += vv[r] * w.y;
+                    }
+                }
+                *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) = make_float4(g0, g1, sv, 0.0f);
+            }
+#pragma unroll
+            for (int idx = 0; idx < 16; ++idx) {
+                pd0[idx] = half_sum_dpp_hi(pd0[idx]);
+                pd1[idx] = half_sum_dpp_hi(pd1[idx]);
+            }
+            if (nl == 31) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long m = tl * 32 + 8 * q + 4 * h + r;
+                        *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) = make_float2(pd0[4 * q + r], pd1[4 * q + r]);
+                    }
+            }
+        }
         }
     };
     if (a.act == SVAE_ACT_TANH) epi(std::integral_constant<int, SVAE_ACT_TANH>());
