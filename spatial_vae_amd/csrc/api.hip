@@ -324,9 +324,9 @@ template <int NT, bool RESID>
 void launch_split_fwd_c(const SplitArgs& a, dim3 grid, int cf, hipStream_t st) {
     constexpr int lds = SplitCfg<NT>::LDS_BYTES;
     switch (cf) {
-        case 1: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 1>), grid, dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 2>), grid, dim3(256), lds, st, a); break;
-        default: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 0>), grid, dim3(256), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 1>), grid, dim3(kSplitWaves * 64), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 2>), grid, dim3(kSplitWaves * 64), lds, st, a); break;
+        default: hipLaunchKernelGGL((dense_split_kernel<NT, 0, RESID, 0>), grid, dim3(kSplitWaves * 64), lds, st, a); break;
     }
 }
 
@@ -334,16 +334,27 @@ template <int NT>
 void launch_split_bwd_c(const SplitArgs& a, dim3 grid, bool first, bool resid, hipStream_t st) {
     constexpr int lds = SplitCfg<NT>::LDS_BYTES;
     if (first) {
-        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 2, true, 0>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((dense_split_kernel<NT, 2, false, 0>), grid, dim3(256), lds, st, a);
+        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 2, true, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
+        else hipLaunchKernelGGL((dense_split_kernel<NT, 2, false, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
     } else {
-        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 1, true, 0>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((dense_split_kernel<NT, 1, false, 0>), grid, dim3(256), lds, st, a);
+        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 1, true, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
+        else hipLaunchKernelGGL((dense_split_kernel<NT, 1, false, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
     }
 }
 
+// one weight matrix -> split fragments in pl.splitW, its scale {s, 1/s} in pl.gscale[2..3]
+void split_weights(const Geo& g, const Plan& pl, const float* W, int transpose, hipStream_t st) {
+    (void)hipMemsetAsync(pl.amax + 1, 0, sizeof(unsigned), st);
+    hipLaunchKernelGGL(split_wamax_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, W, (long)g.H * g.H, pl.amax + 1);
+    hipLaunchKernelGGL(split_wscale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)(pl.amax + 1), pl.gscale + 2);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W, pl.splitW,
+                       g.H, g.Hp, transpose, (const float*)(pl.gscale + 2));
+}
+
+int split_nt(const Geo& g) { return g.ntile % 4 == 0 ? 4 : 2; }  // column tiles per pass (the path needs ntile even)
+
 dim3 split_grid(const Geo& g, int nt) {  // see dense_split_kernel: (xcd, column block, group / 8)
-    const long groups = (g.tiles + 3) / 4;
+    const long groups = (g.tiles + kSplitWaves - 1) / kSplitWaves;
     return dim3((unsigned)(((groups + 7) / 8) * 8 * (g.ntile / nt)));
 }
 
@@ -352,8 +363,7 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
                       int cf, const float* out_w, bool rows_ready, hipStream_t st) {
     {
         Scope prof(K_PREPARE, st);
-        hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W,
-                           pl.splitW, g.H, g.Hp, 0);
+        split_weights(g, pl, W, 0, st);
         if (!rows_ready)  // deeper layers: the previous GEMM wrote fp32 only
             hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, in,
                                pl.splitA, g.tiles, g.Hp, (const float*)nullptr);
@@ -363,14 +373,12 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
     a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = bias; a.resid = in;
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
-    a.aux = nullptr; a.scale = nullptr; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr; a.N = g.N; a.Timg = g.Timg;
-    const int nt = dense_nt_first(g.ntile);
+    a.aux = nullptr; a.scale = nullptr; a.wscale = pl.gscale + 2; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr;
+    a.N = g.N; a.Timg = g.Timg;
+    const int nt = split_nt(g);
     const dim3 grid = split_grid(g, nt);
-    switch (nt) {
-        case 4: resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st); break;
-        case 2: resid ? launch_split_fwd_c<2, true>(a, grid, cf, st) : launch_split_fwd_c<2, false>(a, grid, cf, st); break;
-        default: resid ? launch_split_fwd_c<1, true>(a, grid, cf, st) : launch_split_fwd_c<1, false>(a, grid, cf, st); break;
-    }
+    if (nt == 4) resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st);
+    else resid ? launch_split_fwd_c<2, true>(a, grid, cf, st) : launch_split_fwd_c<2, false>(a, grid, cf, st);
 }
 
 // data gradient of the LAST hidden layer in fp16x3 mode: dh (fp32, scaled by pl.gscale) -> split rows, W^T -> split weights
@@ -378,8 +386,7 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
                         bool first, const PoseArgs& pa, hipStream_t st) {
     {
         Scope prof(K_PREPARE, st);
-        hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W,
-                           pl.splitW, g.H, g.Hp, 1);
+        split_weights(g, pl, W, 1, st);
         hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, dh, pl.splitA,
                            g.tiles, g.Hp, (const float*)pl.gscale);
     }
@@ -388,15 +395,12 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = nullptr; a.resid = dh;
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = nullptr; a.lpart = nullptr; a.Mp = g.Mp;
-    a.aux = aux; a.scale = pl.gscale; a.pose = pa; a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile;
+    a.aux = aux; a.scale = pl.gscale; a.wscale = pl.gscale + 2; a.pose = pa; a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile;
     a.dfpart = pl.dfpart; a.N = g.N; a.Timg = g.Timg;
-    const int nt = dense_nt_first(g.ntile);
+    const int nt = split_nt(g);
     const dim3 grid = split_grid(g, nt);
-    switch (nt) {
-        case 4: launch_split_bwd_c<4>(a, grid, first, resid, st); break;
-        case 2: launch_split_bwd_c<2>(a, grid, first, resid, st); break;
-        default: launch_split_bwd_c<1>(a, grid, first, resid, st); break;
-    }
+    if (nt == 4) launch_split_bwd_c<4>(a, grid, first, resid, st);
+    else launch_split_bwd_c<2>(a, grid, first, resid, st);
 }
 
 template <bool DGRAD>
@@ -558,7 +562,8 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
         hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
-                           logits, row_geo(g), g.C, g.ntile / dense_nt_first(g.ntile), (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0,
+                           logits, row_geo(g), g.C, g.ntile / (split ? split_nt(g) : dense_nt_first(g.ntile)),
+                           (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0,
                            (long)g.Mp);
         return launch_status("svae_decoder_forward");
     }
@@ -685,7 +690,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                g.B, g.Hp, g.Timg);
             if (want_coords)
                 hipLaunchKernelGGL(coords_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, dc,
-                                   g.ntile / dense_nt_first(g.ntile), g.B, g.N, g.Npad, (long)g.Mp);
+                                   g.ntile / ((split_bwd && g.L == 2) ? split_nt(g) : dense_nt_first(g.ntile)), g.B, g.N, g.Npad,
+                                   (long)g.Mp);
         } else {
             const float* dh0 = pl.dh[cur];
             hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0,

@@ -1,11 +1,13 @@
 // fp16x3 split-operand GEMM path (opt-in: SVAE_GEMM=fp16x3) -- fp32-accurate products on the f16 matrix pipe.
 //
-// Every fp32 operand x is carried as two halfs  x ~= hi + lo / 2048,  hi = half(x), lo = half((x - hi) * 2048), and a
-// product a*w is formed as  hi_a*hi_w + (hi_a*lo_w + lo_a*hi_w) / 2048  with fp32 accumulation in the MFMA: the dropped
-// lo*lo term is 2^-22 relative, so the result is as accurate as an fp32 GEMM (measured: same 5e-7 relative error against
-// fp64 as the fp32 MFMA path, tools/split_numerics.py), while v_mfma_f32_32x32x16_f16 runs at 16x the rate of
-// v_mfma_f32_32x32x2_f32: three of them per K=16 step cost 96 cycles where the fp32 form needs 512.
-// Operands must be bounded (|x| < 65504): the path is used after tanh / sigmoid activations only.
+// Every fp32 operand tensor X is carried as two half tensors of s*X,  hi = half(s x), lo = half(s x - hi), with a
+// power-of-two scale s per tensor that puts its largest entries near 2^10..2^14 (so that lo stays a NORMAL half for every
+// entry that matters); a product is formed as  hi_a*hi_w + hi_a*lo_w + lo_a*hi_w  in ONE fp32 MFMA accumulator and the
+// epilogue multiplies by 1/(s_a s_w) (exact).  The dropped lo*lo term is 2^-22 relative: the result is as accurate as an
+// fp32 GEMM (tools/split_numerics.py: 2.8e-7 rms against fp64, the fp32 GEMM's own figure), while
+// v_mfma_f32_32x32x16_f16 runs at 16x the rate of v_mfma_f32_32x32x2_f32: three of them per K=16 step cost 96 cycles
+// where the fp32 form needs 512.  Scales: activations after tanh / sigmoid (|a| <= 1) 2^10; weights 2^floor(log2(8192 /
+// max|W|)) per matrix (split_wscale_kernel); the gradient entering the last hidden layer from a bound (split_scale_kernel).
 //
 // Layouts (all 16-byte = 8-half fragments, addressed in uint4 units):
 //   rows  As[T][kc][part][lane]   T = 32-row tile, kc = 16-feature step, part 0 = hi / 1 = lo, lane = MFMA lane
@@ -21,8 +23,8 @@
 namespace svae {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float kLoScale = 2048.0f;
-constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr float kActScale = 1024.0f;  // activations in [-1, 1]
+constexpr float kActInv = 1.0f / 1024.0f;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 union Frag {  // 8 halfs <-> 16 bytes
@@ -56,13 +58,14 @@ __device__ __forceinline__ void wait_frag(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
 }
 
-__device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo) {
+__device__ __forceinline__ void split8(const float (&x)[8], float sc, uint4& hi, uint4& lo) {
     Frag fh, fl;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 hj = (_Float16)x[j];
+        const float xs = x[j] * sc;  // power of two: exact
+        const _Float16 hj = (_Float16)xs;
         fh.h[j] = hj;
-        fl.h[j] = (_Float16)((x[j] - (float)hj) * kLoScale);
+        fl.h[j] = (_Float16)(xs - (float)hj);
     }
     hi = fh.u;
     lo = fl.u;
@@ -70,7 +73,8 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& hi, uint4& lo
 
 // W (H x H, row-major [out n][in k]) -> Ws for the forward contraction over k: B[k][n] = W[n][k].
 // transpose != 0 packs the data-gradient form instead: contraction over n, B[n][k] = W[n][k].
-__global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ ws, int H, int Hp, int transpose) {
+__global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ ws, int H, int Hp, int transpose,
+                                     const float* __restrict__ wscale) {
     const int ntile = Hp / 32, KC = Hp / 16;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (kc, nt, lane)
     if (idx >= (long)KC * ntile * 64) return;
@@ -84,14 +88,36 @@ __global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restr
         x[j] = (n < H && k < H) ? W[(long)n * H + k] : 0.0f;
     }
     uint4 hi, lo;
-    split8(x, hi, lo);
+    split8(x, wscale[0], hi, lo);
     const long blk = ((long)kc * ntile + nt) * 2;
     ws[blk * 64 + lane] = hi;
     ws[(blk + 1) * 64 + lane] = lo;
 }
 
-// fp32 octet-major plane (element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)) -> As, optionally multiplied by *scale first
-// (gradients are far below the half range: a power-of-two scale brings them into it, the GEMM epilogue divides it out)
+// max |W| of one weight matrix as float bits (non-negative floats order like their bit patterns) ...
+__global__ void split_wamax_kernel(const float* __restrict__ W, long count, unsigned* __restrict__ amax) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float m = i < count ? fabsf(W[i]) : 0.0f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+}
+// ... and {s, 1/s} from it: s = 2^floor(log2(8192 / max|W|))
+__global__ void split_wscale_kernel(const unsigned* __restrict__ amax, float* __restrict__ wscale) {
+    const float wmax = __uint_as_float(amax[0]);
+    float sc = 1.0f;
+    if (wmax > 0.0f && wmax < 3.0e38f) {
+        int e;
+        frexpf(8192.0f / wmax, &e);
+        e = e - 1 < -60 ? -60 : (e - 1 > 60 ? 60 : e - 1);
+        sc = ldexpf(1.0f, e);
+    }
+    wscale[0] = sc;
+    wscale[1] = 1.0f / sc;
+}
+
+// fp32 octet-major plane (element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)) -> As, multiplied by its power-of-two scale
+// (*scale for a gradient, else the activation scale)
 __global__ void split_rows_kernel(const float* __restrict__ in, uint4* __restrict__ as, long tiles, int Hp,
                                   const float* __restrict__ scale) {
     const int KC = Hp / 16;
@@ -103,12 +129,12 @@ __global__ void split_rows_kernel(const float* __restrict__ in, uint4* __restric
     const long m = T * 32 + (lane & 31);
     const int k0 = kc * 16 + 8 * (lane >> 5);
     const float* p = in + ((m >> 3) * Hp + k0) * 8 + (m & 7);
-    const float sc = scale ? scale[0] : 1.0f;
+    const float sc = scale ? scale[0] : kActScale;
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = p[j * 8] * sc;
+    for (int j = 0; j < 8; ++j) x[j] = p[j * 8];
     uint4 hi, lo;
-    split8(x, hi, lo);
+    split8(x, sc, hi, lo);
     const long blk = (T * KC + kc) * 2;
     as[blk * 64 + lane] = hi;
     as[(blk + 1) * 64 + lane] = lo;
@@ -161,7 +187,7 @@ __global__ void __launch_bounds__(256) layer0_fwd_split_kernel(PoseArgs pose, co
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = tile[r][c0 + j];
         uint4 hi, lo;
-        split8(x, hi, lo);
+        split8(x, kActScale, hi, lo);
         const int KC = g.Hp / 16;
         uint4* dst = as + ((T * KC + (f0 >> 4) + kq) * 2) * 64 + lane;
         dst[0] = hi;
@@ -210,7 +236,8 @@ struct SplitArgs {
     long Mp;
     // data gradient (MODE 1 / 2): act' of aux multiplies the result; scale[1] undoes the operand scale
     const float* aux;    // a_{l-1}, fp32 octet-major
-    const float* scale;  // device: {s, 1/s} or null
+    const float* scale;  // device {s, 1/s} of the row operand when it is a gradient; null: an activation (kActScale)
+    const float* wscale; // device {s, 1/s} of the weights
     // MODE 2 (into the coordinate layer): reduced on the spot, see dense_kernel FIRST
     PoseArgs pose;
     const float4* posebuf;
@@ -225,7 +252,10 @@ struct SplitArgs {
 #ifndef SVAE_SPLIT_ABLATE
 #define SVAE_SPLIT_ABLATE 0
 #endif
-constexpr int kSplitG = 4;  // K=16 steps per LDS chunk (the contraction length must be a multiple of 64)
+#ifndef SVAE_SPLIT_G
+#define SVAE_SPLIT_G 2
+#endif
+constexpr int kSplitG = SVAE_SPLIT_G;  // K=16 steps per LDS chunk: the contraction length must be a multiple of 16 G
 
 template <int NT>
 struct SplitCfg {
@@ -236,9 +266,15 @@ struct SplitCfg {
 // MODE 0: out(32 rows x NT*32 cols per wave) = act( As * Ws + bias [+ resid] )            (forward; CF: + partial logits)
 // MODE 1: out = ((As * Ws) / s [+ resid]) * act'(aux)                                      (data gradient, stored)
 // MODE 2: the same value reduced on the spot into the coordinate layer's partial sums      (dense_kernel's FIRST)
-// 4 waves (4 row tiles) share the weight chunks.
+// kSplitWaves waves (row tiles) share the weight chunks: at f16-MFMA speed the vector-memory path (64 B/clk/CU) is the
+// scarce resource -- every wave streams 2 KiB of row fragments per K-step and its share of the 2 KiB x NT weight blocks;
+// eight waves per workgroup instead of four halve the weight share (ablation: the LDS-DMA alone cost 0.09 of 0.32 ms).
+#ifndef SVAE_SPLIT_WAVES
+#define SVAE_SPLIT_WAVES 8
+#endif
+constexpr int kSplitWaves = SVAE_SPLIT_WAVES;
 template <int NT, int MODE, bool RESID, int CF>
-__global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
+__global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void dense_split_kernel(SplitArgs a) {
     static_assert(CF == 0 || MODE == 0, "CF is a forward epilogue");
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     using Cfg = SplitCfg<NT>;
@@ -260,16 +296,16 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
     const long local = blockIdx.x >> 3;
     const int nb = (int)(local % nblk);  // column block of NT tiles
     const long group = (local / nblk) * 8 + (blockIdx.x & 7);
-    const long tile = group * 4 + wave;
+    const long tile = group * kSplitWaves + wave;
     const bool live = tile < a.tiles;
     const long tl = live ? tile : a.tiles - 1;
     const int nchunk = KC / G;
 
-    f32x16 acc[NT], accx[NT];
+    f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; accx[t][r] = 0.0f; }
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     // Weight chunks reach LDS by LDS-DMA issued from asm (glds16), ONE chunk ahead: at the top of chunk c every wave has
     // waited for its own pieces of chunk c, the barrier publishes them and proves that nobody reads the other buffer
@@ -281,15 +317,16 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
     //   step g needs A(g) of this chunk (issued in the previous one): behind it are 2(G-1-g) A loads of that chunk,
     //   this chunk's P pieces and 2g A loads -> vmcnt(2(G-1) + P), one constant for every step;
     //   the barrier needs this wave's pieces of chunk c (issued at the top of chunk c-1): behind them 2G A loads.
-    constexpr int P = BLOCKS / 4;  // 1 KiB pieces per wave and chunk
+    constexpr int P = BLOCKS / kSplitWaves;  // 1 KiB pieces per wave and chunk
+    static_assert(BLOCKS % kSplitWaves == 0, "the chunk must divide over the waves");
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)smem4;
-    // Addresses are prepared once: piece j of this wave is block idx = wave + 4 j of a chunk; its source offset inside
+    // Addresses are prepared once: piece j of this wave is block idx = wave + kSplitWaves j of a chunk; its source offset inside
     // the chunk and its LDS address are loop-invariant, the chunk base advances by a scalar add.  (Computed per piece
     // inside the loop this was ~130 instructions per 48 MFMAs: a third of the kernel.)
     unsigned poff[P], pm0[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        const int idx = wave + 4 * j;
+        const int idx = wave + kSplitWaves * j;
         const int part = idx & 1, t = (idx >> 1) % NT, g = (idx >> 1) / NT;
         poff[j] = (unsigned)((((g * ntile + nb * NT + t) * 2 + part) * 64 + lane) * 16);
         pm0[j] = lds_base + (unsigned)idx * 1024u;  // scalar: wave and the LDS base are SGPR values
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
         if (g == 2) { load_frag_s<0>(abase, off + 4096u, fh.v); load_frag_s<1024>(abase, off + 4096u, fl.v); }
         if (g == 3) { load_frag_s<2048>(abase, off + 4096u, fh.v); load_frag_s<3072>(abase, off + 4096u, fl.v); }
     };
-    static_assert(G == 4, "load_rows addresses four K-steps per chunk");
+    static_assert(G == 2 || G == 4, "load_rows addresses at most four K-steps per chunk");
     Frag rh[G], rl[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -327,10 +364,10 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
         const uint4* buf = smem4 + (c & 1) * (BLOCKS * 64);
         if (SVAE_SPLIT_ABLATE & 16) wait_frag<2 * G + P>(rh[0].v, rl[0].v);
         else wait_frag<2 * G>(rh[0].v, rl[0].v);
-        if (!(SVAE_SPLIT_ABLATE & 4) || c == 0) __syncthreads();
+        if (!(SVAE_SPLIT_ABLATE & (4 | 32)) || c == 0) __syncthreads();
         wchunk += more ? chunk_bytes : 0u;
         aoff += more ? (unsigned)(G * 2048) : 0u;
-        if (!(SVAE_SPLIT_ABLATE & 4)) stage_chunk(wchunk, (unsigned)(((c + 1) & 1) * BLOCKS * 1024));
+        if (!(SVAE_SPLIT_ABLATE & (4 | 64))) stage_chunk(wchunk, (unsigned)(((c + 1) & 1) * BLOCKS * 1024));
         else {
 #pragma unroll
             for (int j = 0; j < P; ++j) asm volatile("s_nop 0" ::: "memory");
@@ -362,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[g].h, bq[cur][0].h, acc[t], 0, 0, 0);
-                accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[g].h, bq[cur][1].h, accx[t], 0, 0, 0);
-                accx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[g].h, bq[cur][0].h, accx[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[g].h, bq[cur][1].h, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[g].h, bq[cur][0].h, acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             load_rows(aoff, g, rh[g], rl[g]);
@@ -404,13 +441,13 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
             for (int r = 0; r < 16; ++r) lp[c][r] = 0.0f;
         const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;
         const long qstride = (long)Hp * 8;
+        const float inv = kActInv * a.wscale[1];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const long off = off0 + q * qstride + (long)t * 32 * 8;
-                float4 v = make_float4(acc[t][4 * q] + accx[t][4 * q] * kLoInv, acc[t][4 * q + 1] + accx[t][4 * q + 1] * kLoInv,
-                                       acc[t][4 * q + 2] + accx[t][4 * q + 2] * kLoInv, acc[t][4 * q + 3] + accx[t][4 * q + 3] * kLoInv);
+                float4 v = make_float4(acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv);
                 if (RESID) {
                     const float4 fr = *reinterpret_cast<const float4*>(a.resid + off);
                     v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
@@ -443,15 +480,12 @@ __global__ __launch_bounds__(256, 2) void dense_split_kernel(SplitArgs a) {
         }
             } else {
         constexpr int NB = NT * 32;
-        const float inv = a.scale ? a.scale[1] : 1.0f;
+        const float inv = (a.scale ? a.scale[1] : kActInv) * a.wscale[1];
         const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;
         const long qstride = (long)Hp * 8;
         auto value = [&](int t, int q) {  // this lane's 4 rows (8q + 4h + 0..3) of column tile t, times act'(a_{l-1})
             const long off = off0 + q * qstride + (long)t * 32 * 8;
-            float4 v = make_float4((acc[t][4 * q] + accx[t][4 * q] * kLoInv) * inv,
-                                   (acc[t][4 * q + 1] + accx[t][4 * q + 1] * kLoInv) * inv,
-                                   (acc[t][4 * q + 2] + accx[t][4 * q + 2] * kLoInv) * inv,
-                                   (acc[t][4 * q + 3] + accx[t][4 * q + 3] * kLoInv) * inv);
+            float4 v = make_float4(acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv);
             if (RESID) {
                 const float4 fr = *reinterpret_cast<const float4*>(a.resid + off);
                 v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
