@@ -62,6 +62,7 @@ struct Plan {
     float* dfpart;  // fused first-layer backward: per-column-block d(coords) (ntile x Mp x 2)
     uint4* splitA;  // fp16x3 mode: the row operand as hi/lo half fragments (Mp x Hp x 4 bytes)
     uint4* splitW;  // fp16x3 mode: one layer's weights as hi/lo half fragments
+    uint4* splitC[2]; // fp16x3 mode: column fragments of the gradient and of a_{l-1} (weight gradient operands)
     float* gscale;  // fp16x3 mode: {s, 1/s} power-of-two scale of the gradient entering the last hidden layer
     unsigned* amax; // fp16x3 mode: max |d loss / d logits| as float bits
     // split geometry
@@ -75,6 +76,11 @@ struct Plan {
 // SVAE_GEMM=fp16x3: hidden-layer GEMMs on the f16 matrix pipe with split (hi + lo/2048) operands, see split.h
 bool split_mode() {
     static const bool on = [] { const char* e = getenv("SVAE_GEMM"); return e && strcmp(e, "fp16x3") == 0; }();
+    return on;
+}
+
+bool split_wgrad_on() {  // SVAE_SPLIT_WGRAD=0 keeps the fp32 weight-gradient kernel in fp16x3 mode
+    static const bool on = [] { const char* e = getenv("SVAE_SPLIT_WGRAD"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -135,11 +141,14 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.sgtile = cw.take<float>((size_t)g.tiles * 2 * g.Hp * 4);
     p.dfpart = cw.take<float>((size_t)g.ntile * g.Mp * 2);
     p.splitA = p.splitW = nullptr;
+    p.splitC[0] = p.splitC[1] = nullptr;
     p.gscale = nullptr;
     p.amax = nullptr;
     if (split_mode()) {
         p.splitA = cw.take<uint4>(MH / 4);
         p.splitW = cw.take<uint4>((size_t)g.Hp * g.Hp / 4);
+        p.splitC[0] = cw.take<uint4>(MH / 4);
+        p.splitC[1] = cw.take<uint4>(MH / 4);
         p.gscale = cw.take<float>(64);
         p.amax = cw.take<unsigned>(64);
     }
@@ -403,6 +412,28 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     else launch_split_bwd_c<2>(a, grid, first, resid, st);
 }
 
+// weight gradient of the LAST hidden layer in fp16x3 mode (operands converted to column fragments first)
+void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const float* aprev, hipStream_t st) {
+    {
+        Scope prof(K_PREPARE, st);
+        hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, dh, pl.splitC[0], g.noct, g.Hp,
+                           (const float*)pl.gscale);
+        hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, aprev, pl.splitC[1], g.noct,
+                           g.Hp, (const float*)nullptr);
+    }
+    Scope prof(K_WGRAD, st);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kSplitWgradLds);
+        attr_set = true;
+    }
+    SplitWgradArgs w;
+    w.dh = pl.splitC[0]; w.ap = pl.splitC[1]; w.slab = pl.slab; w.bslab = pl.bslab; w.gscale = pl.gscale;
+    w.nsteps = (long)g.Mp / 16; w.Hp = g.Hp; w.nblk1 = pl.wg_nblk1;
+    hipLaunchKernelGGL(split_wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), kSplitWgradLds, st, w);
+}
+
 template <bool DGRAD>
 void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
@@ -646,7 +677,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             w.nblk1 = pl.wg_nblk1;
             w.do_p = pl.do_p; w.out_w = p->out_w; w.wpart = pl.wpart; w.bpart = pl.bpart;
             w.Mp = g.Mp; w.H = g.H; w.act = g.act;
-            launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
+            if (split_bwd && l == g.L - 1 && split_wgrad_on()) launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1], st);
+            else launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
             Scope prof(K_WGRAD_REDUCE, st);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
                                grads->hidden_w[l - 1], grads->hidden_b[l - 1], g.H, g.Hp, pl.wg_S);

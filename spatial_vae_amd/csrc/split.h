@@ -560,4 +560,155 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
     else epi(std::integral_constant<int, SVAE_ACT_SIGMOID>());
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient in fp16x3 mode: dW[n][k] = sum_m dh[m][n] a[m][k], both operands as COLUMN fragments
+//   Cs[ms][ft][part][lane]   ms = 16-row step, ft = 32-feature tile, lane = h*32 + f: rows 16 ms + 8 h + (0..7) of
+//                            feature 32 ft + f -- the contraction (rows) runs inside the 16-byte fragment.
+// fp32 octet-major stores exactly those 8 rows contiguously, so the conversion is a straight copy-and-split.
+__global__ void split_cols_kernel(const float* __restrict__ in, uint4* __restrict__ cs, long noct, int Hp,
+                                  const float* __restrict__ scale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (octet, feature)
+    if (idx >= noct * Hp) return;
+    const int f = (int)(idx % Hp);
+    const long o = idx / Hp;
+    const float4* p = reinterpret_cast<const float4*>(in + idx * 8);
+    const float4 v0 = p[0], v1 = p[1];
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    uint4 hi, lo;
+    split8(x, scale ? scale[0] : kActScale, hi, lo);
+    const int FT = Hp / 32;
+    const long blk = (((o >> 1) * FT + (f >> 5)) * 2) * 64 + (o & 1) * 32 + (f & 31);
+    cs[blk] = hi;
+    cs[blk + 64] = lo;
+}
+
+struct SplitWgradArgs {
+    const uint4* dh;     // Cs of the gradient (scaled by *gscale)
+    const uint4* ap;     // Cs of a_{l-1}
+    float* slab;         // [S][Hp][Hp] partial dW
+    float* bslab;        // [S*2][Hp] partial db
+    const float* gscale; // {s, 1/s} of the gradient
+    long nsteps;         // Mp / 16
+    int Hp, nblk1;       // nblk1 = 256-wide blocks per side
+};
+constexpr int kSplitWgradLds = 3 * 32 * 1024;
+
+// One 256 x 256 block of dW per workgroup (blockIdx.x), one range of 16-row steps per blockIdx.y.  Per step the
+// workgroup stages 8 + 8 feature tiles x (hi, lo) = 32 KiB by LDS-DMA (two steps ahead, three buffers); wave (wi, wj)
+// reads its 4 + 4 tiles from LDS and issues 4 x 4 x 3 MFMAs into 256 accumulator registers.
+__global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    asm volatile("s_nop 4" : "+s"(wave));
+    const int wi = wave >> 1, wj = wave & 1;
+    const int nl = lane & 31, h = lane >> 5;
+    const int Hp = a.Hp, FT = Hp / 32;
+    const int bn = blockIdx.x / a.nblk1, bk = blockIdx.x % a.nblk1;
+    const int S = gridDim.y;
+    const long per = (a.nsteps + S - 1) / S;
+    const long s0 = (long)blockIdx.y * per;
+    long s1 = s0 + per;
+    if (s1 > a.nsteps) s1 = a.nsteps;
+    const int nst = s1 > s0 ? (int)(s1 - s0) : 0;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // DMA pieces: block idx = wave + 4 j of a step's 32 (j < 4: gradient tiles, j >= 4: activation tiles)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)smw;
+    unsigned poff[8], pm0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = wave + 4 * j;
+        const int part = idx & 1, tile = (idx >> 1) & 7;
+        int ft = (j < 4 ? bn : bk) * 8 + tile;
+        ft = ft < FT ? ft : FT - 1;  // past the matrix edge: a valid tile, its products are never stored
+        poff[j] = (unsigned)(((ft * 2 + part) * 64 + lane) * 16);
+        pm0[j] = lds_base + (unsigned)idx * 1024u;
+    }
+    const unsigned step_bytes = (unsigned)FT * 2048u;
+    const char* gbase = reinterpret_cast<const char*>(a.dh) + s0 * (long)step_bytes;
+    const char* abase = reinterpret_cast<const char*>(a.ap) + s0 * (long)step_bytes;
+    auto stage = [&](const char* gb, const char* ab, unsigned bufoff) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16_s(j < 4 ? gb : ab, poff[j], pm0[j] + bufoff);
+    };
+    if (nst > 0) {
+        stage(gbase, abase, 0u);
+        const unsigned adv0 = nst > 1 ? step_bytes : 0u;
+        gbase += adv0;
+        abase += adv0;
+        stage(gbase, abase, 32u * 1024u);
+        for (int c = 0; c < nst; ++c) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's pieces of step c (behind them: step c+1's 8)
+            __syncthreads();
+            const unsigned adv = c + 2 < nst ? step_bytes : 0u;  // past the end: re-stage the last step (never read)
+            gbase += adv;
+            abase += adv;
+            stage(gbase, abase, (unsigned)((c + 2) % 3) * 32u * 1024u);
+            const uint4* buf = smw + (c % 3) * 2048;
+            Frag gh[4], gl[4], ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gh[i].u = buf[((wi * 4 + i) * 2) * 64 + lane];
+                gl[i].u = buf[((wi * 4 + i) * 2 + 1) * 64 + lane];
+                ah[i].u = buf[(16 + (wj * 4 + i) * 2) * 64 + lane];
+                al[i].u = buf[(16 + (wj * 4 + i) * 2 + 1) * 64 + lane];
+            }
+            if (wj == 0) {  // bias gradient: column sums of the gradient tiles (VALU, hidden under the MFMAs)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t += (float)gh[i].h[e] + (float)gl[i].h[e];
+                    bs[i] += t;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, ah[j].h, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, al[j].h, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[i].h, ah[j].h, acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // slab[split][n][k]: lane holds column k, registers rows n = (r & 3) + 8 (r >> 2) + 4 h
+    const float ginv = a.gscale[1];
+    const float inv = ginv * kActInv;
+    float* slab = a.slab + (long)blockIdx.y * Hp * Hp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nt = bn * 8 + wi * 4 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kt = bk * 8 + wj * 4 + j;
+            if (nt < FT && kt < FT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    slab[(long)n * Hp + kt * 32 + nl] = acc[i][j][r] * inv;
+                }
+            }
+        }
+    }
+    if (bk == 0 && wj == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nt = bn * 8 + wi * 4 + i;
+            if (nt < FT) a.bslab[((long)blockIdx.y * 2 + h) * Hp + nt * 32 + nl] = bs[i] * ginv;
+        }
+    }
+}
+
 }  // namespace svae
