@@ -62,6 +62,7 @@ struct Plan {
     float* dfpart;  // fused first-layer backward: per-column-block d(coords) (ntile x Mp x 2)
     uint4* splitA;  // fp16x3 mode: the row operand as hi/lo half fragments (Mp x Hp x 4 bytes)
     uint4* splitW;  // fp16x3 mode: one layer's weights as hi/lo half fragments
+    uint4* savedC;    // fp16x3 mode, in `saved`: column fragments of a0 written by the coordinate layer (L == 2)
     uint4* splitC[2]; // fp16x3 mode: column fragments of the gradient and of a_{l-1} (weight gradient operands)
     float* gscale;  // fp16x3 mode: {s, 1/s} power-of-two scale of the gradient entering the last hidden layer
     unsigned* amax; // fp16x3 mode: max |d loss / d logits| as float bits
@@ -79,6 +80,11 @@ bool split_mode() {
     return on;
 }
 
+bool split_l0_on() {  // SVAE_SPLIT_L0=0: the coordinate layer writes fp32 only and conversion passes feed the GEMMs
+    static const bool on = [] { const char* e = getenv("SVAE_SPLIT_L0"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool split_wgrad_on() {  // SVAE_SPLIT_WGRAD=0 keeps the fp32 weight-gradient kernel in fp16x3 mode
     static const bool on = [] { const char* e = getenv("SVAE_SPLIT_WGRAD"); return !(e && e[0] == '0'); }();
     return on;
@@ -89,6 +95,7 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     const size_t MH = (size_t)g.Mp * g.Hp;
     Carver cs(saved);
     for (int l = 0; l < g.L; ++l) p.act[l] = cs.take<float>(MH);
+    p.savedC = split_mode() ? cs.take<uint4>(MH / 4) : nullptr;  // fp16x3: column fragments of a0 for the weight gradient
     p.saved_bytes = cs.off;
 
     p.wg_nblk1 = (g.ntile + 7) / 8;
@@ -413,13 +420,15 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
 }
 
 // weight gradient of the LAST hidden layer in fp16x3 mode (operands converted to column fragments first)
-void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const float* aprev, hipStream_t st) {
+void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const float* aprev, const uint4* aprev_cols,
+                        hipStream_t st) {
     {
         Scope prof(K_PREPARE, st);
         hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, dh, pl.splitC[0], g.noct, g.Hp,
                            (const float*)pl.gscale);
-        hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, aprev, pl.splitC[1], g.noct,
-                           g.Hp, (const float*)nullptr);
+        if (!aprev_cols)  // deeper stacks: a_{L-2} came out of a GEMM epilogue in fp32 only
+            hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, aprev, pl.splitC[1],
+                               g.noct, g.Hp, (const float*)nullptr);
     }
     Scope prof(K_WGRAD, st);
     static bool attr_set = false;
@@ -429,7 +438,7 @@ void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const flo
         attr_set = true;
     }
     SplitWgradArgs w;
-    w.dh = pl.splitC[0]; w.ap = pl.splitC[1]; w.slab = pl.slab; w.bslab = pl.bslab; w.gscale = pl.gscale;
+    w.dh = pl.splitC[0]; w.ap = aprev_cols ? aprev_cols : pl.splitC[1]; w.slab = pl.slab; w.bslab = pl.bslab; w.gscale = pl.gscale;
     w.nsteps = (long)g.Mp / 16; w.Hp = g.Hp; w.nblk1 = pl.wg_nblk1;
     hipLaunchKernelGGL(split_wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), kSplitWgradLds, st, w);
 }
@@ -481,10 +490,10 @@ void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* 
 }
 
 template <int ACT>
-void launch_layer0_fwd_split(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
+void launch_layer0_fwd_split(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, bool saved_ok, hipStream_t st) {
     Scope prof(K_LAYER0_FWD, st);  // Hp is a multiple of 64 here (ntile even)
     hipLaunchKernelGGL((layer0_fwd_split_kernel<ACT>), dim3((unsigned)g.tiles, (unsigned)(g.Hp / 64)), dim3(256), 0, st, pa,
-                       pl.posebuf, pl.tab, a0, pl.splitA, row_geo(g));
+                       pl.posebuf, pl.tab, a0, pl.splitA, (saved_ok && g.L == 2) ? pl.savedC : (uint4*)nullptr, row_geo(g));
 }
 
 template <int C>
@@ -553,11 +562,10 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
     launch_prepare(g, pl, p, pa, z, st);
     // fp16x3: bounded operands only, contraction length a multiple of 64
     const bool split = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0;
-    static const bool l0_env = [] { const char* e = getenv("SVAE_SPLIT_L0"); return !(e && e[0] == '0'); }();
-    const bool split_l0 = l0_env && split && g.L >= 2;
+    const bool split_l0 = split_l0_on() && split && g.L >= 2;
     if (split_l0) {  // a0 leaves the coordinate layer in both forms: no conversion pass before the first GEMM
-        if (g.act == SVAE_ACT_TANH) launch_layer0_fwd_split<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st);
-        else launch_layer0_fwd_split<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st);
+        if (g.act == SVAE_ACT_TANH) launch_layer0_fwd_split<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], saved != nullptr, st);
+        else launch_layer0_fwd_split<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], saved != nullptr, st);
     } else {
         switch (g.act) {
             case SVAE_ACT_TANH: launch_layer0_fwd<SVAE_ACT_TANH>(g, pl, pa, pl.act[0], st); break;
@@ -677,7 +685,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             w.nblk1 = pl.wg_nblk1;
             w.do_p = pl.do_p; w.out_w = p->out_w; w.wpart = pl.wpart; w.bpart = pl.bpart;
             w.Mp = g.Mp; w.H = g.H; w.act = g.act;
-            if (split_bwd && l == g.L - 1 && split_wgrad_on()) launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1], st);
+            if (split_bwd && l == g.L - 1 && split_wgrad_on())
+                launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1], (g.L == 2 && split_l0_on()) ? pl.savedC : (const uint4*)nullptr, st);
             else launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
             Scope prof(K_WGRAD_REDUCE, st);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,

@@ -148,7 +148,7 @@ __global__ void split_rows_kernel(const float* __restrict__ in, uint4* __restric
 template <int ACT>
 __global__ void __launch_bounds__(256) layer0_fwd_split_kernel(PoseArgs pose, const float4* __restrict__ posebuf,
                                                                 const float* __restrict__ tab, float* __restrict__ a0,
-                                                                uint4* __restrict__ as, RowGeo g) {
+                                                                uint4* __restrict__ as, uint4* __restrict__ cs, RowGeo g) {
     __shared__ float tile[32][65];  // [row][feature], padded: both access patterns are bank-conflict-free
     const long T = blockIdx.x;      // 32-row tile
     const int f0 = blockIdx.y * 64; // first feature of this block
@@ -190,6 +190,19 @@ __global__ void __launch_bounds__(256) layer0_fwd_split_kernel(PoseArgs pose, co
         split8(x, kActScale, hi, lo);
         const int KC = g.Hp / 16;
         uint4* dst = as + ((T * KC + (f0 >> 4) + kq) * 2) * 64 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+    }
+    if (cs) {  // column fragments for the weight gradient (kept forward -> backward): thread = (16-row step mq, tile fq, lane)
+        const int mq = threadIdx.x >> 7, fq = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+        const int r0 = 16 * mq + 8 * (lane >> 5), c = 32 * fq + (lane & 31);
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = tile[r0 + j][c];
+        uint4 hi, lo;
+        split8(x, kActScale, hi, lo);
+        const int FT = g.Hp / 32;
+        uint4* dst = cs + (((T * 2 + mq) * FT + (f0 >> 5) + fq) * 2) * 64 + lane;
         dst[0] = hi;
         dst[64] = lo;
     }
