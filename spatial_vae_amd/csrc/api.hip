@@ -139,7 +139,8 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.do_p = cw.take<float>((size_t)g.C * g.Mp);
     p.slab = cw.take<float>((size_t)p.wg_S * g.Hp * g.Hp);
     p.bslab = cw.take<float>((size_t)p.wg_S * 2 * g.Hp);
-    const size_t nparts = (size_t)(p.ob_chunks > p.wg_S ? p.ob_chunks : p.wg_S) * 2;  // out_bwd chunks or wgrad splits
+    size_t nparts = (size_t)(p.ob_chunks > p.wg_S ? p.ob_chunks : p.wg_S) * 2;  // out_bwd chunks or wgrad splits
+    if (split_mode() && nparts < 256 * 4) nparts = 256 * 4;                        // out_bwd_split: up to 256 chunks x 4
     p.wpart = cw.take<float>(nparts * g.C * g.Hp);
     p.bpart = cw.take<float>(nparts * g.C);
     p.sgpart = cw.take<float>((size_t)g.B * p.l0_chunks_per_image * g.Hp * 2 * kSlots);
@@ -399,12 +400,13 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
 
 // data gradient of the LAST hidden layer in fp16x3 mode: dh (fp32, scaled by pl.gscale) -> split rows, W^T -> split weights
 void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const float* W, const float* aux, float* out, bool resid,
-                        bool first, const PoseArgs& pa, hipStream_t st) {
+                        bool first, const PoseArgs& pa, bool rows_ready, hipStream_t st) {
     {
         Scope prof(K_PREPARE, st);
         split_weights(g, pl, W, 1, st);
-        hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, dh, pl.splitA,
-                           g.tiles, g.Hp, (const float*)pl.gscale);
+        if (!rows_ready)
+            hipLaunchKernelGGL(split_rows_kernel, dim3(blocks_for(g.tiles * (g.Hp / 16) * 64)), dim3(256), 0, st, dh, pl.splitA,
+                               g.tiles, g.Hp, (const float*)pl.gscale);
     }
     Scope prof(K_DENSE_DGRAD, st);
     SplitArgs a;
@@ -419,13 +421,41 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     else launch_split_bwd_c<2>(a, grid, first, resid, st);
 }
 
+// output layer backward in fp16x3 mode: dh straight into pl.splitA (rows) and pl.splitC[0] (columns); returns the number
+// of partial sums per column it left in pl.wpart / pl.bpart
+template <int ACT, int C>
+int launch_out_bwd_split_ac(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh32, hipStream_t st) {
+    Scope prof(K_OUT_BWD, st);
+    long chunks = g.tiles < 256 ? g.tiles : 256;
+    const long per = (g.tiles + chunks - 1) / chunks;
+    chunks = (g.tiles + per - 1) / per;
+    const dim3 grid((unsigned)(g.Hp / 64), (unsigned)chunks);
+    if (dh32)
+        hipLaunchKernelGGL((out_bwd_split_kernel<ACT, C, true>), grid, dim3(256), 0, st, a, pl.do_p, p->out_w, dh32, pl.splitA,
+                           pl.splitC[0], pl.wpart, pl.bpart, (const float*)pl.gscale, g.H, g.Hp, (long)g.Mp, g.tiles, per);
+    else
+        hipLaunchKernelGGL((out_bwd_split_kernel<ACT, C, false>), grid, dim3(256), 0, st, a, pl.do_p, p->out_w, dh32, pl.splitA,
+                           pl.splitC[0], pl.wpart, pl.bpart, (const float*)pl.gscale, g.H, g.Hp, (long)g.Mp, g.tiles, per);
+    return (int)chunks * 4;
+}
+template <int ACT>
+int launch_out_bwd_split_a(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh32, hipStream_t st) {
+    switch (g.C) {
+        case 1: return launch_out_bwd_split_ac<ACT, 1>(g, pl, a, p, dh32, st);
+        case 2: return launch_out_bwd_split_ac<ACT, 2>(g, pl, a, p, dh32, st);
+        case 3: return launch_out_bwd_split_ac<ACT, 3>(g, pl, a, p, dh32, st);
+        default: return launch_out_bwd_split_ac<ACT, 4>(g, pl, a, p, dh32, st);
+    }
+}
+
 // weight gradient of the LAST hidden layer in fp16x3 mode (operands converted to column fragments first)
 void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const float* aprev, const uint4* aprev_cols,
-                        hipStream_t st) {
+                        bool cols_ready, hipStream_t st) {
     {
         Scope prof(K_PREPARE, st);
-        hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, dh, pl.splitC[0], g.noct, g.Hp,
-                           (const float*)pl.gscale);
+        if (!cols_ready)
+            hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, dh, pl.splitC[0], g.noct,
+                               g.Hp, (const float*)pl.gscale);
         if (!aprev_cols)  // deeper stacks: a_{L-2} came out of a GEMM epilogue in fp32 only
             hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(g.noct * g.Hp)), dim3(256), 0, st, aprev, pl.splitC[1],
                                g.noct, g.Hp, (const float*)nullptr);
@@ -657,7 +687,18 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     const char* fuse_env = getenv("SVAE_FUSE_OUT");  // opt-in: slower on fp32 MFMA (see wgrad_kernel), saves a 419 MB plane
     const bool fused_out = fuse_env && fuse_env[0] == '1' && g.L >= 2 && !resid &&
                            (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]);
-    if (!fused_out) {
+    // fp16x3 with both GEMMs of the last hidden layer on the f16 pipe: dh leaves out_bwd in their operand forms
+    static const bool ob_env = [] { const char* e = getenv("SVAE_SPLIT_OB"); return !(e && e[0] == '0'); }();
+    const bool split_ob = ob_env && split_bwd && split_wgrad_on() && (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]);
+    if (split_ob) {
+        const float* alast = pl.act[g.L - 1];
+        float* dh32 = resid ? pl.dh[cur] : nullptr;  // only a residual epilogue reads dh itself
+        const int nparts = g.act == SVAE_ACT_TANH ? launch_out_bwd_split_a<SVAE_ACT_TANH>(g, pl, alast, p, dh32, st)
+                                                  : launch_out_bwd_split_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, dh32, st);
+        Scope prof(K_SMALL_BWD, st);
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
+                           grads->out_w, grads->out_b, g.C, g.H, g.Hp, nparts);
+    } else if (!fused_out) {
         const float* alast = pl.act[g.L - 1];
         switch (g.act) {
             case SVAE_ACT_TANH: launch_out_bwd_a<SVAE_ACT_TANH>(g, pl, alast, p, pl.dh[cur], st); break;
@@ -686,7 +727,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             w.do_p = pl.do_p; w.out_w = p->out_w; w.wpart = pl.wpart; w.bpart = pl.bpart;
             w.Mp = g.Mp; w.H = g.H; w.act = g.act;
             if (split_bwd && l == g.L - 1 && split_wgrad_on())
-                launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1], (g.L == 2 && split_l0_on()) ? pl.savedC : (const uint4*)nullptr, st);
+                launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1], (g.L == 2 && split_l0_on()) ? pl.savedC : (const uint4*)nullptr,
+                                   split_ob, st);
             else launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
             Scope prof(K_WGRAD_REDUCE, st);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
@@ -711,7 +753,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         a.do_p = pl.do_p; a.out_w = p->out_w; a.C = g.C;
         fused_first = (l == 1) && g.in_dim == 2;
         if (split_bwd && l == g.L - 1)
-            launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa, st);
+            launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa,
+                               split_ob, st);
         else
             launch_dense<true>(g, a, st, fused_first, last);
         cur ^= 1;

@@ -573,6 +573,91 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
     else epi(std::integral_constant<int, SVAE_ACT_SIGMOID>());
 }
 
+// Output layer backward in fp16x3 mode: dh[m][n] = (sum_c do[m][c] W_o[c][n]) act'(a[m][n]) leaves the pass ALREADY in the
+// two operand forms of the GEMMs that consume it (row fragments for the data gradient, column fragments for the weight
+// gradient, both scaled by gscale[0]) instead of an fp32 plane plus two conversion passes; fp32 is written only when a
+// residual epilogue needs it (KEEP32).  Same LDS-tile scheme as layer0_fwd_split_kernel; a workgroup walks a range of
+// 32-row tiles of one 64-feature block and keeps out_bwd_kernel's partial sums for dW_o / db_o:
+// wpart[(chunk*4 + sub)][c][n], bpart[(chunk*4 + sub)][c], sub = (thread >> 7)*2 + half.
+template <int ACT, int C, bool KEEP32>
+__global__ void __launch_bounds__(256) out_bwd_split_kernel(const float* __restrict__ a, const float* __restrict__ do_p,
+                                                             const float* __restrict__ out_w, float* __restrict__ dh32,
+                                                             uint4* __restrict__ as, uint4* __restrict__ cs,
+                                                             float* __restrict__ wpart, float* __restrict__ bpart,
+                                                             const float* __restrict__ gscale, int H, int Hp, long Mp,
+                                                             long tiles, long tiles_per_chunk) {
+    __shared__ float tile[32][65];
+    const int f0 = blockIdx.x * 64;
+    const int k = (threadIdx.x & 127) >> 1, h = threadIdx.x & 1, osub = threadIdx.x >> 7;
+    const int n = f0 + k;
+    const float sc = gscale[0];
+    float w[C], pw[C], pb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        w[c] = (n < H) ? out_w[c * H + n] : 0.0f;
+        pw[c] = 0.0f;
+        pb[c] = 0.0f;
+    }
+    const int KC = Hp / 16, FT = Hp / 32;
+    const long t0 = (long)blockIdx.y * tiles_per_chunk;
+    const long t1 = (t0 + tiles_per_chunk < tiles) ? t0 + tiles_per_chunk : tiles;
+    for (long T = t0; T < t1; ++T) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int oo = osub + 2 * it;
+            const long o = T * 4 + oo;
+            const long off = (o * Hp + n) * 8 + 4 * h;
+            const float4 av = *reinterpret_cast<const float4*>(a + off);
+            float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float4 d = *reinterpret_cast<const float4*>(do_p + (long)c * Mp + 8 * o + 4 * h);
+                da.x += d.x * w[c]; da.y += d.y * w[c]; da.z += d.z * w[c]; da.w += d.w * w[c];
+                pw[c] += (d.x * av.x + d.y * av.y) + (d.z * av.z + d.w * av.w);
+                pb[c] += (d.x + d.y) + (d.z + d.w);
+            }
+            da.x *= act_grad<ACT>(av.x); da.y *= act_grad<ACT>(av.y);
+            da.z *= act_grad<ACT>(av.z); da.w *= act_grad<ACT>(av.w);
+            if (KEEP32) *reinterpret_cast<float4*>(dh32 + off) = da;
+            const int r = oo * 8 + 4 * h;
+            tile[r][k] = da.x; tile[r + 1][k] = da.y; tile[r + 2][k] = da.z; tile[r + 3][k] = da.w;
+        }
+        __syncthreads();
+        {   // row fragments: thread = (K-step kq of this block's four, lane)
+            const int kq = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int r = lane & 31, c0 = kq * 16 + 8 * (lane >> 5);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = tile[r][c0 + j];
+            uint4 hi, lo;
+            split8(x, sc, hi, lo);
+            uint4* dst = as + ((T * KC + (f0 >> 4) + kq) * 2) * 64 + lane;
+            dst[0] = hi;
+            dst[64] = lo;
+        }
+        {   // column fragments: thread = (16-row step mq, tile fq, lane)
+            const int mq = threadIdx.x >> 7, fq = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+            const int r0 = 16 * mq + 8 * (lane >> 5), c = 32 * fq + (lane & 31);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = tile[r0 + j][c];
+            uint4 hi, lo;
+            split8(x, sc, hi, lo);
+            uint4* dst = cs + (((T * 2 + mq) * FT + (f0 >> 5) + fq) * 2) * 64 + lane;
+            dst[0] = hi;
+            dst[64] = lo;
+        }
+        __syncthreads();
+    }
+    const long part = (long)blockIdx.y * 4 + osub * 2 + h;
+#pragma unroll
+    for (int c = 0; c < C; ++c) wpart[(part * C + c) * Hp + n] = pw[c];
+    if (n == 0) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) bpart[part * C + c] = pb[c];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient in fp16x3 mode: dW[n][k] = sum_m dh[m][n] a[m][k], both operands as COLUMN fragments
 //   Cs[ms][ft][part][lane]   ms = 16-row step, ft = 32-feature tile, lane = h*32 + f: rows 16 ms + 8 h + (0..7) of
