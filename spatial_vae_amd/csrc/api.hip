@@ -362,10 +362,9 @@ void launch_split_bwd_c(const SplitArgs& a, dim3 grid, bool first, bool resid, h
 // one weight matrix -> split fragments in pl.splitW, its scale {s, 1/s} in pl.gscale[2..3]
 void split_weights(const Geo& g, const Plan& pl, const float* W, int transpose, hipStream_t st) {
     (void)hipMemsetAsync(pl.amax + 1, 0, sizeof(unsigned), st);
-    hipLaunchKernelGGL(split_wamax_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, W, (long)g.H * g.H, pl.amax + 1);
-    hipLaunchKernelGGL(split_wscale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)(pl.amax + 1), pl.gscale + 2);
+    hipLaunchKernelGGL(split_wamax_kernel, dim3(64), dim3(256), 0, st, W, (long)g.H * g.H, pl.amax + 1);
     hipLaunchKernelGGL(split_weights_kernel, dim3(blocks_for((long)(g.Hp / 16) * g.ntile * 64)), dim3(256), 0, st, W, pl.splitW,
-                       g.H, g.Hp, transpose, (const float*)(pl.gscale + 2));
+                       g.H, g.Hp, transpose, (const unsigned*)(pl.amax + 1), pl.gscale + 2);
 }
 
 int split_nt(const Geo& g) { return g.ntile % 4 == 0 ? 4 : 2; }  // column tiles per pass (the path needs ntile even)
@@ -426,7 +425,7 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
 template <int ACT, int C>
 int launch_out_bwd_split_ac(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh32, hipStream_t st) {
     Scope prof(K_OUT_BWD, st);
-    long chunks = g.tiles < 256 ? g.tiles : 256;
+    long chunks = g.tiles < 128 ? g.tiles : 128;
     const long per = (g.tiles + chunks - 1) / chunks;
     chunks = (g.tiles + per - 1) / per;
     const dim3 grid((unsigned)(g.Hp / 64), (unsigned)chunks);

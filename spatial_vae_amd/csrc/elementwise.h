@@ -204,9 +204,15 @@ __global__ void dlogits_kernel(const float* __restrict__ logits, const float* __
         m = fabsf(v);
     }
     if (amax) {  // fp16x3 mode: max |do| (non-negative floats order like their bit patterns; max is order-independent)
+        __shared__ float red[4];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            if (m > 0.0f) atomicMax(amax, __float_as_uint(m));  // one atomic per block, none for all-zero blocks
+        }
     }
 }
 

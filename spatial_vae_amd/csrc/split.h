@@ -71,10 +71,35 @@ __device__ __forceinline__ void split8(const float (&x)[8], float sc, uint4& hi,
     lo = fl.u;
 }
 
+// max |W| of one weight matrix as float bits (non-negative floats order like their bit patterns): 64 blocks, one atomic each
+__global__ void split_wamax_kernel(const float* __restrict__ W, long count, unsigned* __restrict__ amax) {
+    __shared__ float red[4];
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(W[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+// s = 2^floor(log2(8192 / max|W|)) from those bits
+__device__ __forceinline__ float weight_scale(unsigned amax_bits) {
+    const float wmax = __uint_as_float(amax_bits);
+    float sc = 1.0f;
+    if (wmax > 0.0f && wmax < 3.0e38f) {
+        int e;
+        frexpf(8192.0f / wmax, &e);
+        e = e - 1 < -60 ? -60 : (e - 1 > 60 ? 60 : e - 1);
+        sc = ldexpf(1.0f, e);
+    }
+    return sc;
+}
+
 // W (H x H, row-major [out n][in k]) -> Ws for the forward contraction over k: B[k][n] = W[n][k].
 // transpose != 0 packs the data-gradient form instead: contraction over n, B[n][k] = W[n][k].
+// (every thread derives the matrix scale from the amax bits; thread 0 publishes {s, 1/s} for the GEMM epilogue)
 __global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restrict__ ws, int H, int Hp, int transpose,
-                                     const float* __restrict__ wscale) {
+                                     const unsigned* __restrict__ amax, float* __restrict__ wscale) {
     const int ntile = Hp / 32, KC = Hp / 16;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (kc, nt, lane)
     if (idx >= (long)KC * ntile * 64) return;
@@ -87,33 +112,16 @@ __global__ void split_weights_kernel(const float* __restrict__ W, uint4* __restr
         const int n = transpose ? con : col, k = transpose ? col : con;
         x[j] = (n < H && k < H) ? W[(long)n * H + k] : 0.0f;
     }
+    const float sc = weight_scale(amax[0]);
+    if (idx == 0) {
+        wscale[0] = sc;
+        wscale[1] = 1.0f / sc;
+    }
     uint4 hi, lo;
-    split8(x, wscale[0], hi, lo);
+    split8(x, sc, hi, lo);
     const long blk = ((long)kc * ntile + nt) * 2;
     ws[blk * 64 + lane] = hi;
     ws[(blk + 1) * 64 + lane] = lo;
-}
-
-// max |W| of one weight matrix as float bits (non-negative floats order like their bit patterns) ...
-__global__ void split_wamax_kernel(const float* __restrict__ W, long count, unsigned* __restrict__ amax) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    float m = i < count ? fabsf(W[i]) : 0.0f;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
-}
-// ... and {s, 1/s} from it: s = 2^floor(log2(8192 / max|W|))
-__global__ void split_wscale_kernel(const unsigned* __restrict__ amax, float* __restrict__ wscale) {
-    const float wmax = __uint_as_float(amax[0]);
-    float sc = 1.0f;
-    if (wmax > 0.0f && wmax < 3.0e38f) {
-        int e;
-        frexpf(8192.0f / wmax, &e);
-        e = e - 1 < -60 ? -60 : (e - 1 > 60 ? 60 : e - 1);
-        sc = ldexpf(1.0f, e);
-    }
-    wscale[0] = sc;
-    wscale[1] = 1.0f / sc;
 }
 
 // fp32 octet-major plane (element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)) -> As, multiplied by its power-of-two scale
