@@ -1,8 +1,8 @@
-# usage: bash tools/profile_round.sh <tag>  -- kernel-trace stats of the bench command + HBM traffic counter passes
+# usage: [SVAE_GEMM=fp16x3] bash tools/profile_round.sh <tag>  -- kernel-trace stats of the bench command + HBM traffic counter passes
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r01}
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --gemm ${SVAE_GEMM:-fp32} > $R/gpurun_out/${TAG}_stats.log 2>&1
 tail -1 $R/gpurun_out/${TAG}_stats.log | cut -c1-160
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_fetch -- python3 $R/tools/kbench.py --iters 2 > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_write -- python3 $R/tools/kbench.py --iters 2 > $R/gpurun_out/${TAG}_write.log 2>&1
