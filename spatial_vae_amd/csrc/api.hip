@@ -64,6 +64,7 @@ struct Plan {
     uint4* splitW;  // fp16x3 mode: one layer's weights as hi/lo half fragments
     uint4* savedC;    // fp16x3 mode, in `saved`: column fragments of a0 written by the coordinate layer (L == 2)
     uint4* splitC[2]; // fp16x3 mode: column fragments of the gradient and of a_{l-1} (weight gradient operands)
+    float* hbpart;  // fp16x3 mode: partial column sums of dh_{L-1} from out_bwd_split_kernel (nparts x Hp)
     float* gscale;  // fp16x3 mode: {s, 1/s} power-of-two scale of the gradient entering the last hidden layer
     unsigned* amax; // fp16x3 mode: max |d loss / d logits| as float bits
     // split geometry
@@ -150,6 +151,7 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.dfpart = cw.take<float>((size_t)g.ntile * g.Mp * 2);
     p.splitA = p.splitW = nullptr;
     p.splitC[0] = p.splitC[1] = nullptr;
+    p.hbpart = nullptr;
     p.gscale = nullptr;
     p.amax = nullptr;
     if (split_mode()) {
@@ -157,6 +159,7 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
         p.splitW = cw.take<uint4>((size_t)g.Hp * g.Hp / 4);
         p.splitC[0] = cw.take<uint4>(MH / 4);
         p.splitC[1] = cw.take<uint4>(MH / 4);
+        p.hbpart = cw.take<float>((size_t)128 * 4 * g.Hp);
         p.gscale = cw.take<float>(64);
         p.amax = cw.take<unsigned>(64);
     }
@@ -431,10 +434,12 @@ int launch_out_bwd_split_ac(const Geo& g, const Plan& pl, const float* a, const 
     const dim3 grid((unsigned)(g.Hp / 64), (unsigned)chunks);
     if (dh32)
         hipLaunchKernelGGL((out_bwd_split_kernel<ACT, C, true>), grid, dim3(256), 0, st, a, pl.do_p, p->out_w, dh32, pl.splitA,
-                           pl.splitC[0], pl.wpart, pl.bpart, (const float*)pl.gscale, g.H, g.Hp, (long)g.Mp, g.tiles, per);
+                           pl.splitC[0], pl.wpart, pl.bpart, pl.hbpart, (const float*)pl.gscale, g.H, g.Hp, (long)g.Mp, g.tiles,
+                           per);
     else
         hipLaunchKernelGGL((out_bwd_split_kernel<ACT, C, false>), grid, dim3(256), 0, st, a, pl.do_p, p->out_w, dh32, pl.splitA,
-                           pl.splitC[0], pl.wpart, pl.bpart, (const float*)pl.gscale, g.H, g.Hp, (long)g.Mp, g.tiles, per);
+                           pl.splitC[0], pl.wpart, pl.bpart, pl.hbpart, (const float*)pl.gscale, g.H, g.Hp, (long)g.Mp, g.tiles,
+                           per);
     return (int)chunks * 4;
 }
 template <int ACT>
@@ -462,14 +467,18 @@ void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     Scope prof(K_WGRAD, st);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kSplitWgradLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_wgrad_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSplitWgradLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&split_wgrad_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSplitWgradLds);
         attr_set = true;
     }
     SplitWgradArgs w;
     w.dh = pl.splitC[0]; w.ap = aprev_cols ? aprev_cols : pl.splitC[1]; w.slab = pl.slab; w.bslab = pl.bslab; w.gscale = pl.gscale;
-    w.nsteps = (long)g.Mp / 16; w.Hp = g.Hp; w.nblk1 = pl.wg_nblk1;
-    hipLaunchKernelGGL(split_wgrad_kernel, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), dim3(256), kSplitWgradLds, st, w);
+    w.nsteps = (long)g.Mp / 16; w.Hp = g.Hp; w.nblk1 = pl.wg_nblk1; w.S = pl.wg_S;
+    const dim3 grid(pl.wg_nblk1 * pl.wg_nblk1 * pl.wg_S);
+    if (cols_ready) hipLaunchKernelGGL(split_wgrad_kernel<false>, grid, dim3(256), kSplitWgradLds, st, w);  // db: out_bwd_split
+    else hipLaunchKernelGGL(split_wgrad_kernel<true>, grid, dim3(256), kSplitWgradLds, st, w);
 }
 
 template <bool DGRAD>
@@ -687,6 +696,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     const bool fused_out = fuse_env && fuse_env[0] == '1' && g.L >= 2 && !resid &&
                            (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]);
     // fp16x3 with both GEMMs of the last hidden layer on the f16 pipe: dh leaves out_bwd in their operand forms
+    int ob_nparts = 0;
     static const bool ob_env = [] { const char* e = getenv("SVAE_SPLIT_OB"); return !(e && e[0] == '0'); }();
     const bool split_ob = ob_env && split_bwd && split_wgrad_on() && (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]);
     if (split_ob) {
@@ -694,6 +704,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         float* dh32 = resid ? pl.dh[cur] : nullptr;  // only a residual epilogue reads dh itself
         const int nparts = g.act == SVAE_ACT_TANH ? launch_out_bwd_split_a<SVAE_ACT_TANH>(g, pl, alast, p, dh32, st)
                                                   : launch_out_bwd_split_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, dh32, st);
+        ob_nparts = nparts;
         Scope prof(K_SMALL_BWD, st);
         hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
                            grads->out_w, grads->out_b, g.C, g.H, g.Hp, nparts);
@@ -730,8 +741,13 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                    split_ob, st);
             else launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
             Scope prof(K_WGRAD_REDUCE, st);
+            const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
-                               grads->hidden_w[l - 1], grads->hidden_b[l - 1], g.H, g.Hp, pl.wg_S);
+                               grads->hidden_w[l - 1], db_elsewhere ? (float*)nullptr : grads->hidden_b[l - 1], g.H, g.Hp,
+                               pl.wg_S);
+            if (db_elsewhere && grads->hidden_b[l - 1])
+                hipLaunchKernelGGL(colsum_reduce_kernel, dim3(g.Hp / 32), dim3(256), 0, st, pl.hbpart, grads->hidden_b[l - 1],
+                                   g.H, g.Hp, ob_nparts);
             if (last)
                 hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
                                    grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.wg_S * 2);

@@ -592,8 +592,8 @@ __global__ void __launch_bounds__(256) out_bwd_split_kernel(const float* __restr
                                                              const float* __restrict__ out_w, float* __restrict__ dh32,
                                                              uint4* __restrict__ as, uint4* __restrict__ cs,
                                                              float* __restrict__ wpart, float* __restrict__ bpart,
-                                                             const float* __restrict__ gscale, int H, int Hp, long Mp,
-                                                             long tiles, long tiles_per_chunk) {
+                                                             float* __restrict__ hbpart, const float* __restrict__ gscale,
+                                                             int H, int Hp, long Mp, long tiles, long tiles_per_chunk) {
     __shared__ float tile[32][65];
     const int f0 = blockIdx.x * 64;
     const int k = (threadIdx.x & 127) >> 1, h = threadIdx.x & 1, osub = threadIdx.x >> 7;
@@ -606,6 +606,7 @@ __global__ void __launch_bounds__(256) out_bwd_split_kernel(const float* __restr
         pw[c] = 0.0f;
         pb[c] = 0.0f;
     }
+    float hb = 0.0f;  // this thread's share of db_{L-1}[n] = sum_m dh[m][n] (the weight-gradient kernel no longer sums it)
     const int KC = Hp / 16, FT = Hp / 32;
     const long t0 = (long)blockIdx.y * tiles_per_chunk;
     const long t1 = (t0 + tiles_per_chunk < tiles) ? t0 + tiles_per_chunk : tiles;
@@ -627,6 +628,7 @@ __global__ void __launch_bounds__(256) out_bwd_split_kernel(const float* __restr
             da.x *= act_grad<ACT>(av.x); da.y *= act_grad<ACT>(av.y);
             da.z *= act_grad<ACT>(av.z); da.w *= act_grad<ACT>(av.w);
             if (KEEP32) *reinterpret_cast<float4*>(dh32 + off) = da;
+            hb += (da.x + da.y) + (da.z + da.w);
             const int r = oo * 8 + 4 * h;
             tile[r][k] = da.x; tile[r + 1][k] = da.y; tile[r + 2][k] = da.z; tile[r + 3][k] = da.w;
         }
@@ -660,9 +662,27 @@ __global__ void __launch_bounds__(256) out_bwd_split_kernel(const float* __restr
     const long part = (long)blockIdx.y * 4 + osub * 2 + h;
 #pragma unroll
     for (int c = 0; c < C; ++c) wpart[(part * C + c) * Hp + n] = pw[c];
+    hbpart[part * Hp + n] = hb;
     if (n == 0) {
 #pragma unroll
         for (int c = 0; c < C; ++c) bpart[part * C + c] = pb[c];
+    }
+}
+
+// db[n] = sum over parts of hbpart[part][n], fixed order (8 interleaved chains per column, combined in LDS)
+__global__ void colsum_reduce_kernel(const float* __restrict__ hbpart, float* __restrict__ db, int H, int Hp, int nparts) {
+    __shared__ float red[8][33];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + col;
+    float s = 0.0f;
+    for (int i = pl; i < nparts; i += 8) s += hbpart[(long)i * Hp + n];
+    red[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && n < H) {
+        float t = red[0][col];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += red[j][col];
+        db[n] = t;
     }
 }
 
@@ -695,13 +715,14 @@ struct SplitWgradArgs {
     float* bslab;        // [S*2][Hp] partial db
     const float* gscale; // {s, 1/s} of the gradient
     long nsteps;         // Mp / 16
-    int Hp, nblk1;       // nblk1 = 256-wide blocks per side
+    int Hp, nblk1, S;    // nblk1 = 256-wide blocks per side, S = row-range splits
 };
 constexpr int kSplitWgradLds = 3 * 32 * 1024;
 
 // One 256 x 256 block of dW per workgroup (blockIdx.x), one range of 16-row steps per blockIdx.y.  Per step the
 // workgroup stages 8 + 8 feature tiles x (hi, lo) = 32 KiB by LDS-DMA (two steps ahead, three buffers); wave (wi, wj)
 // reads its 4 + 4 tiles from LDS and issues 4 x 4 x 3 MFMAs into 256 accumulator registers.
+template <bool BIAS>  // BIAS: also sum the gradient's columns (db); false when out_bwd_split_kernel already did
 __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -710,10 +731,22 @@ __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
     const int wi = wave >> 1, wj = wave & 1;
     const int nl = lane & 31, h = lane >> 5;
     const int Hp = a.Hp, FT = Hp / 32;
-    const int bn = blockIdx.x / a.nblk1, bk = blockIdx.x % a.nblk1;
-    const int S = gridDim.y;
+    // 1-D grid over (block of dW, row-range split).  The nblk^2 blocks of one split read the same rows of both operands:
+    // when the split count is a multiple of 8 they get workgroup ids congruent mod 8, i.e. ONE XCD and its L2, so the
+    // operands come from HBM once instead of nblk times (the kernel is HBM-bound at f16-MFMA speed).
+    const int S = a.S, nb2 = a.nblk1 * a.nblk1;
+    int blk, split;
+    if (S % 8 == 0) {
+        const int local = blockIdx.x >> 3;
+        blk = local % nb2;
+        split = (local / nb2) * 8 + (blockIdx.x & 7);
+    } else {
+        blk = blockIdx.x % nb2;
+        split = blockIdx.x / nb2;
+    }
+    const int bn = blk / a.nblk1, bk = blk % a.nblk1;
     const long per = (a.nsteps + S - 1) / S;
-    const long s0 = (long)blockIdx.y * per;
+    const long s0 = (long)split * per;
     long s1 = s0 + per;
     if (s1 > a.nsteps) s1 = a.nsteps;
     const int nst = s1 > s0 ? (int)(s1 - s0) : 0;
@@ -760,15 +793,17 @@ __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
             abase += adv;
             stage(gbase, abase, (unsigned)((c + 2) % 3) * 32u * 1024u);
             const uint4* buf = smw + (c % 3) * 2048;
-            Frag gh[4], gl[4], ah[4], al[4];
+            // one wave per SIMD: nothing else hides the LDS latency, so the activation fragments of column tile j+1 are
+            // read while the 12 MFMAs of tile j run (sched_barrier pins the order the source states)
+            Frag gh[4], gl[4], ah[2], al[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 gh[i].u = buf[((wi * 4 + i) * 2) * 64 + lane];
                 gl[i].u = buf[((wi * 4 + i) * 2 + 1) * 64 + lane];
-                ah[i].u = buf[(16 + (wj * 4 + i) * 2) * 64 + lane];
-                al[i].u = buf[(16 + (wj * 4 + i) * 2 + 1) * 64 + lane];
             }
-            if (wj == 0) {  // bias gradient: column sums of the gradient tiles (VALU, hidden under the MFMAs)
+            ah[0].u = buf[(16 + (wj * 4) * 2) * 64 + lane];
+            al[0].u = buf[(16 + (wj * 4) * 2 + 1) * 64 + lane];
+            if (BIAS && wj == 0) {  // bias gradient: column sums of the gradient tiles
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float t = 0.0f;
@@ -778,13 +813,20 @@ __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, ah[j].h, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, al[j].h, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[i].h, ah[j].h, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                if (j + 1 < 4) {
+                    ah[(j + 1) & 1].u = buf[(16 + (wj * 4 + j + 1) * 2) * 64 + lane];
+                    al[(j + 1) & 1].u = buf[(16 + (wj * 4 + j + 1) * 2 + 1) * 64 + lane];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, ah[j & 1].h, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, al[j & 1].h, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[i].h, ah[j & 1].h, acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -792,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
     // slab[split][n][k]: lane holds column k, registers rows n = (r & 3) + 8 (r >> 2) + 4 h
     const float ginv = a.gscale[1];
     const float inv = ginv * kActInv;
-    float* slab = a.slab + (long)blockIdx.y * Hp * Hp;
+    float* slab = a.slab + (long)split * Hp * Hp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int nt = bn * 8 + wi * 4 + i;
@@ -808,11 +850,11 @@ __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
             }
         }
     }
-    if (bk == 0 && wj == 0) {
+    if (BIAS && bk == 0 && wj == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nt = bn * 8 + wi * 4 + i;
-            if (nt < FT) a.bslab[((long)blockIdx.y * 2 + h) * Hp + nt * 32 + nl] = bs[i] * ginv;
+            if (nt < FT) a.bslab[((long)split * 2 + h) * Hp + nt * 32 + nl] = bs[i] * ginv;
         }
     }
 }

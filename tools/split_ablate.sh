@@ -2,7 +2,7 @@
 export SVAE_GEMM=fp16x3
 for v in main ab1 ab2 ab3; do
   cp build/libsvae_$v.so spatial_vae_amd/libsvae_hip.so
-  timeout -k 10 200 python bench.py --no-cpu-baseline --steps 20 > gpurun_out/bench_$v.json 2> gpurun_out/bench_$v.err
+  timeout -k 10 200 python bench.py --gemm fp16x3 --no-secondary --no-cpu-baseline --steps 20 > gpurun_out/bench_$v.json 2> gpurun_out/bench_$v.err
   python - <<PY
 import json
 d = json.load(open("gpurun_out/bench_$v.json"))
