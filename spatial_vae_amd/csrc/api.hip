@@ -371,6 +371,11 @@ void split_weights(const Geo& g, const Plan& pl, const float* W, int transpose, 
 }
 
 int split_nt(const Geo& g) { return g.ntile % 4 == 0 ? 4 : 2; }  // column tiles per pass (the path needs ntile even)
+int split_nt_fwd(const Geo& g) {  // SVAE_SPLIT_NT8=1: 8 tiles per forward pass (half the row-operand traffic, but two waves
+                                  // per SIMD instead of four: measured 0.33 vs 0.29 ms at cfg 2, so off by default)
+    static const bool nt8 = [] { const char* e = getenv("SVAE_SPLIT_NT8"); return e && e[0] == '1'; }();
+    return (nt8 && g.ntile % 8 == 0) ? 8 : split_nt(g);
+}
 
 dim3 split_grid(const Geo& g, int nt) {  // see dense_split_kernel: (xcd, column block, group / 8)
     const long groups = (g.tiles + kSplitWaves - 1) / kSplitWaves;
@@ -394,9 +399,10 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
     a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
     a.aux = nullptr; a.scale = nullptr; a.wscale = pl.gscale + 2; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr;
     a.N = g.N; a.Timg = g.Timg;
-    const int nt = split_nt(g);
+    const int nt = split_nt_fwd(g);
     const dim3 grid = split_grid(g, nt);
-    if (nt == 4) resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st);
+    if (nt == 8) resid ? launch_split_fwd_c<8, true>(a, grid, cf, st) : launch_split_fwd_c<8, false>(a, grid, cf, st);
+    else if (nt == 4) resid ? launch_split_fwd_c<4, true>(a, grid, cf, st) : launch_split_fwd_c<4, false>(a, grid, cf, st);
     else resid ? launch_split_fwd_c<2, true>(a, grid, cf, st) : launch_split_fwd_c<2, false>(a, grid, cf, st);
 }
 
@@ -639,7 +645,7 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
         hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
-                           logits, row_geo(g), g.C, g.ntile / (split ? split_nt(g) : dense_nt_first(g.ntile)),
+                           logits, row_geo(g), g.C, g.ntile / (split ? split_nt_fwd(g) : dense_nt_first(g.ntile)),
                            (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0,
                            (long)g.Mp);
         return launch_status("svae_decoder_forward");
