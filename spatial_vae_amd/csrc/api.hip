@@ -86,6 +86,11 @@ bool split_l0_on() {  // SVAE_SPLIT_L0=0: the coordinate layer writes fp32 only 
     return on;
 }
 
+bool split_chain_on() {
+    static const bool on = [] { const char* e = getenv("SVAE_SPLIT_CHAIN"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool split_wgrad_on() {  // SVAE_SPLIT_WGRAD=0 keeps the fp32 weight-gradient kernel in fp16x3 mode
     static const bool on = [] { const char* e = getenv("SVAE_SPLIT_WGRAD"); return !(e && e[0] == '0'); }();
     return on;
@@ -397,7 +402,8 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
     a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = bias; a.resid = in;
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
-    a.aux = nullptr; a.scale = nullptr; a.wscale = pl.gscale + 2; a.posebuf = nullptr; a.tab = nullptr; a.sgtile = nullptr;
+    a.aux = nullptr; a.scale = nullptr; a.wscale = pl.gscale + 2; a.amax_out = nullptr; a.posebuf = nullptr; a.tab = nullptr;
+    a.sgtile = nullptr;
     a.N = g.N; a.Timg = g.Timg;
     const int nt = split_nt_fwd(g);
     const dim3 grid = split_grid(g, nt);
@@ -421,12 +427,19 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = nullptr; a.resid = dh;
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = nullptr; a.lpart = nullptr; a.Mp = g.Mp;
-    a.aux = aux; a.scale = pl.gscale; a.wscale = pl.gscale + 2; a.pose = pa; a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile;
+    a.aux = aux; a.scale = pl.gscale; a.wscale = pl.gscale + 2; a.pose = pa;
+    a.amax_out = nullptr;
+    if (!first) {  // the result is the next (lower) layer's gradient: track its largest entry for that layer's scale
+        (void)hipMemsetAsync(pl.amax + 2, 0, sizeof(unsigned), st);
+        a.amax_out = pl.amax + 2;
+    } a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile;
     a.dfpart = pl.dfpart; a.N = g.N; a.Timg = g.Timg;
     const int nt = split_nt(g);
     const dim3 grid = split_grid(g, nt);
     if (nt == 4) launch_split_bwd_c<4>(a, grid, first, resid, st);
     else launch_split_bwd_c<2>(a, grid, first, resid, st);
+    if (!first)  // scale of the plane just written, for the layer below (stream order: after the GEMM, before its consumers)
+        hipLaunchKernelGGL(split_scale_amax_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)(pl.amax + 2), pl.gscale);
 }
 
 // output layer backward in fp16x3 mode: dh straight into pl.splitA (rows) and pl.splitC[0] (columns); returns the number
@@ -731,6 +744,9 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     bool fused_first = false;
     for (int l = g.L - 1; l >= 1; --l) {
         const bool last = fused_out && l == g.L - 1;
+        // fp16x3 runs down the stack: every split data gradient leaves the scale of its result for the layer below
+        // (SVAE_SPLIT_CHAIN=0: only the last hidden layer)
+        const bool split_here = split_bwd && (l == g.L - 1 || split_chain_on());
         if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1]) {
             WgradArgs w;
             w.dh = last ? pl.act[l] : pl.dh[cur];
@@ -742,9 +758,10 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             w.nblk1 = pl.wg_nblk1;
             w.do_p = pl.do_p; w.out_w = p->out_w; w.wpart = pl.wpart; w.bpart = pl.bpart;
             w.Mp = g.Mp; w.H = g.H; w.act = g.act;
-            if (split_bwd && l == g.L - 1 && split_wgrad_on())
-                launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1], (g.L == 2 && split_l0_on()) ? pl.savedC : (const uint4*)nullptr,
-                                   split_ob, st);
+            if (split_here && split_wgrad_on())
+                launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1],
+                                   (l == 1 && g.L == 2 && split_l0_on()) ? pl.savedC : (const uint4*)nullptr,
+                                   split_ob && l == g.L - 1, st);
             else launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
             Scope prof(K_WGRAD_REDUCE, st);
             const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
@@ -773,9 +790,9 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
         a.do_p = pl.do_p; a.out_w = p->out_w; a.C = g.C;
         fused_first = (l == 1) && g.in_dim == 2;
-        if (split_bwd && l == g.L - 1)
+        if (split_here)
             launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa,
-                               split_ob, st);
+                               split_ob && l == g.L - 1, st);
         else
             launch_dense<true>(g, a, st, fused_first, last);
         cur ^= 1;
@@ -795,7 +812,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                g.B, g.Hp, g.Timg);
             if (want_coords)
                 hipLaunchKernelGGL(coords_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, dc,
-                                   g.ntile / ((split_bwd && g.L == 2) ? split_nt(g) : dense_nt_first(g.ntile)), g.B, g.N, g.Npad,
+                                   g.ntile / ((split_bwd && (g.L == 2 || split_chain_on())) ? split_nt(g) : dense_nt_first(g.ntile)), g.B, g.N,
+                                   g.Npad,
                                    (long)g.Mp);
         } else {
             const float* dh0 = pl.dh[cur];

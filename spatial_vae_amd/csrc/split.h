@@ -243,6 +243,20 @@ __global__ void split_scale_kernel(const unsigned* __restrict__ amax_do_bits, co
     }
 }
 
+// {s, 1/s} for a gradient plane whose largest entry is known: s = 2^floor(log2(16384 / max))
+__global__ void split_scale_amax_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) {
+    const float m = __uint_as_float(amax_bits[0]);
+    float sc = 1.0f;
+    if (m > 0.0f && m < 3.0e38f) {
+        int e;
+        frexpf(16384.0f / m, &e);
+        e = e - 1 < -60 ? -60 : (e - 1 > 60 ? 60 : e - 1);
+        sc = ldexpf(1.0f, e);
+    }
+    scale[0] = sc;
+    scale[1] = 1.0f / sc;
+}
+
 struct SplitArgs {
     const uint4* as;     // row operand, split
     const uint4* ws;     // weights, split
@@ -259,6 +273,7 @@ struct SplitArgs {
     const float* aux;    // a_{l-1}, fp32 octet-major
     const float* scale;  // device {s, 1/s} of the row operand when it is a gradient; null: an activation (kActScale)
     const float* wscale; // device {s, 1/s} of the weights
+    unsigned* amax_out;  // MODE 1: max |result| as float bits (the next layer's gradient scale derives from it), or null
     // MODE 2 (into the coordinate layer): reduced on the spot, see dense_kernel FIRST
     PoseArgs pose;
     const float4* posebuf;
@@ -516,11 +531,20 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
             return v;
         };
         if constexpr (MODE == 1) {
+            float vmax = 0.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = value(t, q);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = value(t, q);
+                    *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = v;
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            if (a.amax_out) {  // one atomic per wave; non-negative floats order like their bit patterns
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+                if (lane == 0 && vmax > 0.0f) atomicMax(a.amax_out, __float_as_uint(vmax));
+            }
         } else {
             // coordinates of this lane's 16 rows (row 8q + 4h + r of the tile), wave-uniform image
             const int b = (int)(tl / a.Timg);

@@ -70,6 +70,7 @@ def main():
         avg = ms / cnt
         extra = "  %.1f TFLOP/s algorithmic" % (gf / avg) if k in ("dense_fwd", "dense_dgrad", "wgrad") else ""
         print("%-14s %8.4f ms x %d%s" % (k, avg, cnt, extra))
+    print("total decoder kernel time per fwd+bwd: %.4f ms" % (sum(ms for ms, _ in prof.values()) / args.iters))
 
 
 if __name__ == "__main__":
