@@ -86,6 +86,11 @@ bool split_l0_on() {  // SVAE_SPLIT_L0=0: the coordinate layer writes fp32 only 
     return on;
 }
 
+// fp16x3, two hidden activations' worth of net (L == 2), plain coordinates, no residual: every consumer of a0 takes a
+// fragment form (forward GEMM: rows; weight gradient and the fused first-layer epilogue: columns), so the coordinate layer
+// skips the fp32 plane.  Forward and backward evaluate the same predicate.
+bool split_a0_fragments_only(const Geo& g);
+
 bool split_chain_on() {
     static const bool on = [] { const char* e = getenv("SVAE_SPLIT_CHAIN"); return !(e && e[0] == '0'); }();
     return on;
@@ -94,6 +99,16 @@ bool split_chain_on() {
 bool split_wgrad_on() {  // SVAE_SPLIT_WGRAD=0 keeps the fp32 weight-gradient kernel in fp16x3 mode
     static const bool on = [] { const char* e = getenv("SVAE_SPLIT_WGRAD"); return !(e && e[0] == '0'); }();
     return on;
+}
+
+bool split_a0_fragments_only(const Geo& g) {
+    // opt-in (SVAE_SPLIT_A0=1): saves the 419 MB plane and 0.03 ms in the coordinate layer but costs the fused epilogue
+    // 0.08 ms (8-byte strided fragment reads + conversions): a memory option, not a speed one
+    static const bool on = [] { const char* e = getenv("SVAE_SPLIT_A0"); return e && e[0] == '1'; }();
+    const char* fuse = getenv("SVAE_FUSE_OUT");
+    return on && split_mode() && split_l0_on() && split_wgrad_on() && !(fuse && fuse[0] == '1') &&
+           (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0 && g.L == 2 && g.in_dim == 2 &&
+           !(g.flags & SVAE_FLAG_RESID);
 }
 
 Plan make_plan(const Geo& g, void* saved, void* ws) {
@@ -402,7 +417,7 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
     a.as = pl.splitA; a.ws = pl.splitW; a.out = out; a.bias = bias; a.resid = in;
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = out_w; a.lpart = pl.dfpart; a.Mp = g.Mp;
-    a.aux = nullptr; a.scale = nullptr; a.wscale = pl.gscale + 2; a.amax_out = nullptr; a.posebuf = nullptr; a.tab = nullptr;
+    a.aux = nullptr; a.auxc = nullptr; a.scale = nullptr; a.wscale = pl.gscale + 2; a.amax_out = nullptr; a.posebuf = nullptr; a.tab = nullptr;
     a.sgtile = nullptr;
     a.N = g.N; a.Timg = g.Timg;
     const int nt = split_nt_fwd(g);
@@ -428,6 +443,7 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     a.tiles = g.tiles; a.Hp = g.Hp; a.H = g.H; a.act = g.act;
     a.out_w = nullptr; a.lpart = nullptr; a.Mp = g.Mp;
     a.aux = aux; a.scale = pl.gscale; a.wscale = pl.gscale + 2; a.pose = pa;
+    a.auxc = (first && split_a0_fragments_only(g)) ? pl.savedC : nullptr;
     a.amax_out = nullptr;
     if (!first) {  // the result is the next (lower) layer's gradient: track its largest entry for that layer's scale
         (void)hipMemsetAsync(pl.amax + 2, 0, sizeof(unsigned), st);
@@ -550,7 +566,8 @@ template <int ACT>
 void launch_layer0_fwd_split(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, bool saved_ok, hipStream_t st) {
     Scope prof(K_LAYER0_FWD, st);  // Hp is a multiple of 64 here (ntile even)
     hipLaunchKernelGGL((layer0_fwd_split_kernel<ACT>), dim3((unsigned)g.tiles, (unsigned)(g.Hp / 64)), dim3(256), 0, st, pa,
-                       pl.posebuf, pl.tab, a0, pl.splitA, (saved_ok && g.L == 2) ? pl.savedC : (uint4*)nullptr, row_geo(g));
+                       pl.posebuf, pl.tab, split_a0_fragments_only(g) ? (float*)nullptr : a0, pl.splitA,
+                       (saved_ok && g.L == 2) ? pl.savedC : (uint4*)nullptr, row_geo(g));
 }
 
 template <int C>

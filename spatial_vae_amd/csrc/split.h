@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) layer0_fwd_split_kernel(PoseArgs pose, co
             tile[oo * 8 + 4 * h + e][k] = out[e];
         }
         const long o = T * 4 + oo;
-        *reinterpret_cast<float4*>(a0 + ((o * g.Hp + f0 + k) * 8 + 4 * h)) = make_float4(out[0], out[1], out[2], out[3]);
+        if (a0) *reinterpret_cast<float4*>(a0 + ((o * g.Hp + f0 + k) * 8 + 4 * h)) = make_float4(out[0], out[1], out[2], out[3]);
     }
     __syncthreads();
     {   // fragments: thread = (K-step kq of this block's four, lane): row lane & 31, features 16 kq + 8 (lane >> 5) + j
@@ -271,6 +271,7 @@ struct SplitArgs {
     long Mp;
     // data gradient (MODE 1 / 2): act' of aux multiplies the result; scale[1] undoes the operand scale
     const float* aux;    // a_{l-1}, fp32 octet-major
+    const uint4* auxc;   // ... or its column fragments (MODE 2 when the coordinate layer wrote no fp32 plane)
     const float* scale;  // device {s, 1/s} of the row operand when it is a gradient; null: an activation (kActScale)
     const float* wscale; // device {s, 1/s} of the weights
     unsigned* amax_out;  // MODE 1: max |result| as float bits (the next layer's gradient scale derives from it), or null
@@ -526,7 +527,19 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
                 const float4 fr = *reinterpret_cast<const float4*>(a.resid + off);
                 v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
             }
-            const float4 ax = *reinterpret_cast<const float4*>(a.aux + off);
+            float4 ax;
+            if (MODE == 2 && a.auxc) {
+                // rows 8q + 4h + (0..3) of column (tile t, nl): halfs 4h..4h+3 of the fragment of 16-row step 2 tl + (q >> 1),
+                // octet q & 1 -- a = (hi + lo) / 2^10
+                const uint4* fr = a.auxc + ((((tl * 2 + (q >> 1)) * (Hp / 32) + nb * NT + t) * 2) * 64 + (q & 1) * 32 + nl);
+                union { uint2 u; _Float16 f[4]; } ph, pl;
+                ph.u = reinterpret_cast<const uint2*>(fr)[h];
+                pl.u = reinterpret_cast<const uint2*>(fr + 64)[h];
+                ax = make_float4(((float)ph.f[0] + (float)pl.f[0]) * kActInv, ((float)ph.f[1] + (float)pl.f[1]) * kActInv,
+                                 ((float)ph.f[2] + (float)pl.f[2]) * kActInv, ((float)ph.f[3] + (float)pl.f[3]) * kActInv);
+            } else {
+                ax = *reinterpret_cast<const float4*>(a.aux + off);
+            }
             v.x *= act_grad<ACT>(ax.x); v.y *= act_grad<ACT>(ax.y); v.z *= act_grad<ACT>(ax.z); v.w *= act_grad<ACT>(ax.w);
             return v;
         };
