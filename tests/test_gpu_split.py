@@ -27,3 +27,9 @@ def test_parity_suites_pass_in_fp16x3_mode():
 def test_parity_with_conversion_passes_instead_of_fused_producers():
     """SVAE_SPLIT_L0=0 / SVAE_SPLIT_OB=0: fp32 planes + conversion kernels feed the same GEMMs (deeper stacks use this)."""
     _run({"SVAE_SPLIT_L0": "0", "SVAE_SPLIT_OB": "0"}, ["tests/test_gpu_parity.py"])
+
+
+def test_parity_with_fragments_only_a0():
+    """SVAE_SPLIT_A0=1: the coordinate layer writes no fp32 plane, the fused first-layer epilogue reads act' from the column
+    fragments (a memory option)."""
+    _run({"SVAE_SPLIT_A0": "1"}, ["tests/test_gpu_parity.py"])
