@@ -753,9 +753,19 @@ __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, float
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx < (long)H * H) {
         const int n = idx / H, k = idx % H;
-        float s = 0.0f;
-        for (int i = 0; i < S; ++i) s += slab[((long)i * Hp + n) * Hp + k];
-        if (dW) dW[idx] = s;
+        // four interleaved chains (fixed order: deterministic), so that several loads are in flight per thread
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        const float* p = slab + (long)n * Hp + k;
+        const long st = (long)Hp * Hp;
+        int i = 0;
+        for (; i + 3 < S; i += 4) {
+            s0 += p[(long)i * st];
+            s1 += p[(long)(i + 1) * st];
+            s2 += p[(long)(i + 2) * st];
+            s3 += p[(long)(i + 3) * st];
+        }
+        for (; i < S; ++i) s0 += p[(long)i * st];
+        if (dW) dW[idx] = (s0 + s1) + (s2 + s3);
     }
     if (idx < H && db) {
         float s = 0.0f;
