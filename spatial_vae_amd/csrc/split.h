@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
     };
     // row operand: wave-uniform tile base in SGPRs + per-lane byte offset; K-step g at +2048 g, lo at +1024
     const char* abase = reinterpret_cast<const char*>(a.as + (((SVAE_SPLIT_ABLATE & 1) ? 0 : tl) * KC) * 2 * 64);
-    unsigned aoff = (unsigned)lane * 16u;  // chunk 0
+    const unsigned aoff = (unsigned)lane * 16u;  // this lane inside a 1 KiB block; chunk c starts at + c * G * 2048
     auto load_rows = [&](unsigned off, int g, Frag& fh, Frag& fl) {
         if (g == 0) { load_frag_s<0>(abase, off, fh.v); load_frag_s<1024>(abase, off, fl.v); }
         if (g == 1) { load_frag_s<2048>(abase, off, fh.v); load_frag_s<3072>(abase, off, fl.v); }
@@ -384,72 +384,92 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
         if (g == 3) { load_frag_s<2048>(abase, off + 4096u, fh.v); load_frag_s<3072>(abase, off + 4096u, fl.v); }
     };
     static_assert(G == 2 || G == 4, "load_rows addresses at most four K-steps per chunk");
-    Frag rh[G], rl[G];
+    // Row fragments are re-issued AD chunks ahead (ring slots stay compile-time constants: the chunk loop is unrolled by
+    // AD, its body one straight-line block).  AD = 2 was measured for the fused first-layer variant, which runs at two
+    // waves per SIMD and waits on memory 42 % of its wave time: no change (0.356 ms either way), so one chunk it stays.
+    constexpr int AD = 1;
+    Frag rh[AD][G], rl[AD][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        rh[g].v = (u32x4){0u, 0u, 0u, 0u};
-        rl[g].v = (u32x4){0u, 0u, 0u, 0u};
-    }
-    stage_chunk(wchunk, 0u);
-#pragma unroll
-    for (int g = 0; g < G; ++g) load_rows(aoff, g, rh[g], rl[g]);
-#pragma unroll
-    for (int g = 0; g < G; ++g) wait_frag<0>(rh[g].v, rl[g].v);
-
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;  // the last chunk re-stages itself into the idle buffer (never read)
-        const uint4* buf = smem4 + (c & 1) * (BLOCKS * 64);
-        if (SVAE_SPLIT_ABLATE & 16) wait_frag<2 * G + P>(rh[0].v, rl[0].v);
-        else wait_frag<2 * G>(rh[0].v, rl[0].v);
-        if (!(SVAE_SPLIT_ABLATE & (4 | 32)) || c == 0) __syncthreads();
-        wchunk += more ? chunk_bytes : 0u;
-        aoff += more ? (unsigned)(G * 2048) : 0u;
-        if (!(SVAE_SPLIT_ABLATE & (4 | 64))) stage_chunk(wchunk, (unsigned)(((c + 1) & 1) * BLOCKS * 1024));
-        else {
-#pragma unroll
-            for (int j = 0; j < P; ++j) asm volatile("s_nop 0" ::: "memory");
-        }
-        // weight fragments are read kBD column tiles ahead of the MFMAs that use them (a ring of kBD + 1 register pairs)
-        constexpr int kBD = 2, kBR = kBD + 1;
-        Frag bq[kBR][2];
-#pragma unroll
-        for (int i = 0; i < kBD; ++i) {
-            if (i < G * NT) {
-                bq[i][0].u = buf[(i * 2) * 64 + lane];
-                bq[i][1].u = buf[(i * 2 + 1) * 64 + lane];
-            }
-        }
+    for (int u = 0; u < AD; ++u)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            __builtin_amdgcn_sched_barrier(0);
-            wait_frag<2 * (G - 1) + P>(rh[g].v, rl[g].v);
+            rh[u][g].v = (u32x4){0u, 0u, 0u, 0u};
+            rl[u][g].v = (u32x4){0u, 0u, 0u, 0u};
+        }
+    stage_chunk(wchunk, 0u);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int it = g * NT + t;
-                const int cur = (SVAE_SPLIT_ABLATE & 8) ? 0 : it % kBR, nxt = (it + kBD) % kBR;
-                const int ni = it + kBD;  // the (step, tile) read now, used kBD tiles later
-                if (ni < G * NT && !(SVAE_SPLIT_ABLATE & 8)) {
-                    bq[nxt][0].u = buf[(ni * 2) * 64 + lane];
-                    bq[nxt][1].u = buf[(ni * 2 + 1) * 64 + lane];
+    for (int u = 0; u < AD; ++u) {
+        const int cu = u < nchunk ? u : nchunk - 1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) load_rows(aoff + (unsigned)(cu * G * 2048), g, rh[u][g], rl[u][g]);
+    }
+#pragma unroll
+    for (int u = 0; u < AD; ++u)
+#pragma unroll
+        for (int g = 0; g < G; ++g) wait_frag<0>(rh[u][g].v, rl[u][g].v);
+
+    for (int c0 = 0; c0 < nchunk; c0 += AD) {  // nchunk = ntile is even whenever this path is taken
+#pragma unroll
+        for (int u = 0; u < AD; ++u) {
+            const int c = c0 + u;
+            const bool more = c + 1 < nchunk;  // the last chunk re-stages itself into the idle buffer (never read)
+            const uint4* buf = smem4 + (c & 1) * (BLOCKS * 64);
+            if (SVAE_SPLIT_ABLATE & 16) wait_frag<2 * G + P>(rh[u][0].v, rl[u][0].v);
+            else wait_frag<2 * G>(rh[u][0].v, rl[u][0].v);
+            if (!(SVAE_SPLIT_ABLATE & (4 | 32)) || c == 0) __syncthreads();
+            wchunk += more ? chunk_bytes : 0u;
+            const int cn = c + AD < nchunk ? c + AD : nchunk - 1;  // the chunk whose row fragments are fetched now
+            const unsigned anext = aoff + (unsigned)(cn * G * 2048);
+            if (!(SVAE_SPLIT_ABLATE & (4 | 64))) stage_chunk(wchunk, (unsigned)(((c + 1) & 1) * BLOCKS * 1024));
+            else {
+#pragma unroll
+                for (int j = 0; j < P; ++j) asm volatile("s_nop 0" ::: "memory");
+            }
+            // weight fragments are read kBD column tiles ahead of the MFMAs that use them (a ring of kBD + 1 register pairs)
+            constexpr int kBD = 2, kBR = kBD + 1;
+            Frag bq[kBR][2];
+#pragma unroll
+            for (int i = 0; i < kBD; ++i) {
+                if (i < G * NT) {
+                    bq[i][0].u = buf[(i * 2) * 64 + lane];
+                    bq[i][1].u = buf[(i * 2 + 1) * 64 + lane];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                __builtin_amdgcn_sched_barrier(0);
+                // behind A(g) of this chunk: the rest of its issue chunk, AD-1 whole chunks, this chunk's pieces and loads
+                wait_frag<2 * (G - 1) + (AD - 1) * (P + 2 * G) + P>(rh[u][g].v, rl[u][g].v);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int it = g * NT + t;
+                    const int cur = (SVAE_SPLIT_ABLATE & 8) ? 0 : it % kBR, nxt = (it + kBD) % kBR;
+                    const int ni = it + kBD;  // the (step, tile) read now, used kBD tiles later
+                    if (ni < G * NT && !(SVAE_SPLIT_ABLATE & 8)) {
+                        bq[nxt][0].u = buf[(ni * 2) * 64 + lane];
+                        bq[nxt][1].u = buf[(ni * 2 + 1) * 64 + lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[u][g].h, bq[cur][0].h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[u][g].h, bq[cur][1].h, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[u][g].h, bq[cur][0].h, acc[t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[g].h, bq[cur][0].h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[g].h, bq[cur][1].h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[g].h, bq[cur][0].h, acc[t], 0, 0, 0);
+                load_rows(anext, g, rh[u][g], rl[u][g]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_rows(aoff, g, rh[g], rl[g]);
         }
     }
     {   // drain: the last fragments and pieces are in flight and never used
         unsigned sink = 0;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            wait_frag<0>(rh[g].v, rl[g].v);
-            sink += rh[g].v[0] + rl[g].v[0];
-        }
+        for (int u = 0; u < AD; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                wait_frag<0>(rh[u][g].v, rl[u][g].v);
+                sink += rh[u][g].v[0] + rl[u][g].v[0];
+            }
         if (a.tiles < 0) a.out[0] = __uint_as_float(sink);  // never true: ties the registers
     }
     __syncthreads();
