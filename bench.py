@@ -180,6 +180,7 @@ def main():
 
     from spatial_vae_amd import _lib, dp
     from spatial_vae_amd import elbo as E
+    _lib.set_gemm_mode(args.gemm)  # explicit (svae_gemm_mode_set); the environment variable covers child processes
 
     rank, world, local = dp.init_process_group(device_is_gpu=True)
     if world != args.gpus:

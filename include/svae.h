@@ -234,6 +234,19 @@ int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, cons
 int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, svae_stream_t stream);
 
 /*
+ * How the hidden-layer GEMMs are computed.  SVAE_GEMM_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products.
+ * SVAE_GEMM_FP16X3: every operand as two half tensors (hi + lo, power-of-two scaled), three f16 MFMAs per product with
+ * fp32 accumulation -- as accurate as an fp32 GEMM, ~1.8x faster per training step; taken for tanh /
+ * sigmoid nets whose width is a multiple of 64, fp32 kernels otherwise.  The mode changes svae_saved_bytes and
+ * svae_workspace_bytes: set it before sizing buffers, and do not change it between a forward call and its backward call.
+ * Without a call the environment variable SVAE_GEMM (fp16x3 | anything else) decides at first use.
+ */
+#define SVAE_GEMM_FP32 0
+#define SVAE_GEMM_FP16X3 1
+int svae_gemm_mode_set(int mode);
+int svae_gemm_mode_get(void);
+
+/*
  * Optional per-kernel timing (bench.py's roofline figure).  While enabled (on = 1: only the three MFMA
  * GEMM kernels, on = 2: every kernel, 0 = off), kernel launches of
  * this library are bracketed by two HIP events recorded on the launch stream; svae_profile_read

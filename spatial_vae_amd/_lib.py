@@ -89,6 +89,9 @@ def lib():
     L.svae_rotate_bicubic.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svae_ctf_filter.restype = ctypes.c_int
     L.svae_ctf_filter.argtypes = [vp, vp, i32, i32, i32, ctypes.c_double, vp]
+    L.svae_gemm_mode_set.restype = ctypes.c_int
+    L.svae_gemm_mode_set.argtypes = [ctypes.c_int]
+    L.svae_gemm_mode_get.restype = ctypes.c_int
     L.svae_profile_enable.restype = ctypes.c_int
     L.svae_profile_enable.argtypes = [ctypes.c_int]
     L.svae_profile_read.restype = ctypes.c_int
@@ -104,6 +107,16 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("svae: %s (code %d)" % (lib().svae_last_error().decode(), rc))
+
+
+def set_gemm_mode(name):
+    """'fp32' (fp32 MFMA) or 'fp16x3' (split-operand f16 MFMA, fp32-accurate).  Call before any decoder call of the process:
+    buffer sizes depend on it."""
+    check(lib().svae_gemm_mode_set({"fp32": 0, "fp16x3": 1}[name]))
+
+
+def gemm_mode():
+    return ("fp32", "fp16x3")[lib().svae_gemm_mode_get()]
 
 
 def profile_enable(level):

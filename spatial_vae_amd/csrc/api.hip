@@ -76,9 +76,16 @@ struct Plan {
 };
 
 // SVAE_GEMM=fp16x3: hidden-layer GEMMs on the f16 matrix pipe with split (hi + lo/2048) operands, see split.h
+std::mutex g_prof_mu;  // guards the profiler records and the mode word
+// -1 = not chosen yet (first use takes SVAE_GEMM from the environment), 0 = fp32 MFMA, 1 = fp16x3; svae_gemm_mode_set()
+int g_gemm_mode = -1;
 bool split_mode() {
-    static const bool on = [] { const char* e = getenv("SVAE_GEMM"); return e && strcmp(e, "fp16x3") == 0; }();
-    return on;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("SVAE_GEMM");
+        g_gemm_mode = (e && strcmp(e, "fp16x3") == 0) ? 1 : 0;
+    }
+    return g_gemm_mode == 1;
 }
 
 bool split_l0_on() {  // SVAE_SPLIT_L0=0: the coordinate layer writes fp32 only and conversion passes feed the GEMMs
@@ -229,7 +236,6 @@ const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense
                                                  "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
                                                  "gaussian", "latent", "adam", "augment"};
 struct ProfRec { hipEvent_t a, b; int kind; };
-std::mutex g_prof_mu;
 int g_prof_level = 0;  // 0 off, 1 = the three MFMA GEMM kernels only, 2 = every kernel
 std::vector<ProfRec> g_prof_used, g_prof_free;
 
@@ -974,6 +980,15 @@ int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t
     hipLaunchKernelGGL(ctf_filter_kernel, dim3(count), dim3(256), lds, st, params, filters, n, m, scale);
     return launch_status("svae_ctf_filter");
 }
+
+int svae_gemm_mode_set(int mode) {
+    if (mode != SVAE_GEMM_FP32 && mode != SVAE_GEMM_FP16X3) return fail(SVAE_E_INVALID, "svae_gemm_mode_set: unknown mode %d", mode);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_gemm_mode = mode;
+    return SVAE_OK;
+}
+
+int svae_gemm_mode_get(void) { return split_mode() ? SVAE_GEMM_FP16X3 : SVAE_GEMM_FP32; }
 
 int svae_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -181,3 +181,20 @@ def test_data_parallel_allreduce_gloo_world2(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count("err") == 2
+
+
+def test_gemm_mode_switch_is_validated_and_needs_no_gpu(monkeypatch):
+    """svae_gemm_mode_set / _get (include/svae.h): default from SVAE_GEMM, explicit set, bad values refused."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); from spatial_vae_amd import _lib; L = _lib.lib();"
+            "assert _lib.gemm_mode() == os.environ.get('WANT'); _lib.set_gemm_mode('fp16x3'); assert _lib.gemm_mode() == 'fp16x3';"
+            "_lib.set_gemm_mode('fp32'); assert _lib.gemm_mode() == 'fp32'; rc = L.svae_gemm_mode_set(7); assert rc != 0;"
+            "assert b'unknown mode' in L.svae_last_error(); print('ok')") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_val, want in ((None, "fp32"), ("fp16x3", "fp16x3"), ("nonsense", "fp32")):
+        env = dict(os.environ, WANT=want)
+        env.pop("SVAE_GEMM", None)
+        if env_val is not None:
+            env["SVAE_GEMM"] = env_val
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
