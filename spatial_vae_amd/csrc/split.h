@@ -7,7 +7,8 @@
 // fp32 GEMM (tools/split_numerics.py: 2.8e-7 rms against fp64, the fp32 GEMM's own figure), while
 // v_mfma_f32_32x32x16_f16 runs at 16x the rate of v_mfma_f32_32x32x2_f32: three of them per K=16 step cost 96 cycles
 // where the fp32 form needs 512.  Scales: activations after tanh / sigmoid (|a| <= 1) 2^10; weights 2^floor(log2(8192 /
-// max|W|)) per matrix (split_wscale_kernel); the gradient entering the last hidden layer from a bound (split_scale_kernel).
+// max|W|)) per matrix (split_wamax_kernel + weight_scale); the gradient entering the last hidden layer from a bound
+// (split_scale_kernel), the gradients further down from the tracked maximum of the plane (split_scale_amax_kernel).
 //
 // Layouts (all 16-byte = 8-half fragments, addressed in uint4 units):
 //   rows  As[T][kc][part][lane]   T = 32-row tile, kc = 16-feature step, part 0 = hi / 1 = lo, lane = MFMA lane
@@ -15,6 +16,8 @@
 //                                 One (T, kc, part) block is 1 KiB: a wave loads it with one global_load_dwordx4.
 //   weights Ws[kc][nt][part][lane] nt = 32-column tile: contraction indices 16 kc + 8 h + (0..7) of column 32 nt + r.
 //                                 One block is 1 KiB and goes to LDS verbatim: ds_read_b128 is lane-linear, conflict-free.
+//   columns Cs[ms][ft][part][lane] ms = 16-row step, ft = 32-feature tile, lane = h*32 + f: rows 16 ms + 8 h + (0..7) of
+//                                 feature 32 ft + f (both operands of the weight gradient, whose contraction runs over rows).
 #pragma once
 #include "common.h"
 #include "dense.h"        // glds16
