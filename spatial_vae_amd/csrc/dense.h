@@ -166,6 +166,11 @@ struct DenseCfg {
 #ifndef SVAE_NT4_WAVES
 #define SVAE_NT4_WAVES 3
 #endif
+// the forward variant that also contracts with W_o (CF) keeps 168 registers in its epilogue.  Sizing it for 4 waves per
+// SIMD (the loop itself needs 124; the overflow then spills in the epilogue only) was measured: 0.938 vs 0.92 ms, so 3.
+#ifndef SVAE_CF_WAVES
+#define SVAE_CF_WAVES 3
+#endif
 // waves per SIMD the register allocation is sized for: 1 at NT = 16 (256 accumulators), 2 at NT = 8, and at
 // NT <= 4 three for the plain kernels (the fused FIRST / LASTD variants keep more values live: two)
 template <int NT, bool FUSED>
@@ -174,7 +179,7 @@ struct DenseOcc {
 };
 
 template <int NT, bool DGRAD, bool RESID, bool FIRST = false, bool LASTD = false, int CF = 0>
-__global__ __launch_bounds__(256, (DenseOcc<NT, (FIRST || LASTD)>::value)) void dense_kernel(DenseArgs a) {
+__global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOcc<NT, (FIRST || LASTD)>::value)) void dense_kernel(DenseArgs a) {
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(CF == 0 || (!DGRAD && CF <= 2), "CF is a forward epilogue for at most two output channels");
     static_assert(!LASTD || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
