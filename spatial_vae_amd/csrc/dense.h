@@ -89,6 +89,17 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_byte_addr
         : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same piece with a wave-uniform base pointer in SGPRs and a 32-bit per-lane byte offset: no 64-bit VALU address
+// arithmetic per piece.  (An SGPR operand of inline asm is invisible to hipcc's hazard recognizer: the base must not be
+// written by a VALU instruction -- v_readfirstlane -- within 5 instructions of the DMA; tools/check_asm_loads.py checks.)
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+        : "memory");
+}
 
 // Row operand of one 4-octet chunk: 16 dwords per lane at byte offsets 256*octet + 32*kstep from p.
 // Also asm, so that EVERY vector-memory operation of the main loop is invisible to hipcc's waitcnt
@@ -214,15 +225,25 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-        // weight chunk c (G contraction octets x NT column tiles, 1 KiB slabs) -> LDS buffer buf
+        // weight chunk c (G contraction octets x NT column tiles, 1 KiB slabs) -> LDS buffer buf.  Piece j of this wave
+        // is slab idx = wave + 4 j of the chunk: its byte offset inside the chunk and its LDS address are loop-invariant
+        // (prepared here), the chunk base is one scalar multiply-add on the kernel argument.
+        constexpr int PW = NINSTR / 4;
+        unsigned poff[PW], pm0[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int idx = wave + 4 * j;
+            const int gl = idx / NT, tt = idx % NT;
+            poff[j] = (unsigned)(((gl * ntile + nb * NT + tt) * 256 + lane * 4) * 4);
+            pm0[j] = lds_base + (unsigned)idx * 1024u;
+        }
+        const unsigned chunk_bytes = (unsigned)(G * ntile) * 1024u;
+        auto stage_piece = [&](int c, int buf, int j) {
+            glds16_s(reinterpret_cast<const char*>(a.wp) + (long)c * chunk_bytes, poff[j], pm0[j] + (unsigned)(buf * CHUNK) * 4u);
+        };
         auto stage = [&](int c, int buf) {
 #pragma unroll
-            for (int j = 0; j < NINSTR / 4; ++j) {
-                const int idx = wave + 4 * j;
-                const int gl = idx / NT, tt = idx % NT;
-                const float* src = a.wp + ((long)(c * G + gl) * ntile + nb * NT + tt) * 256 + lane * 4;
-                glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK + idx * 256) * 4u));
-            }
+            for (int j = 0; j < PW; ++j) stage_piece(c, buf, j);
         };
         // B fragments of contraction octet o: NT x 16 bytes per lane (4 k-steps each), conflict-free
         auto read_b = [&](int o, float4 (&b)[NT]) {
@@ -261,12 +282,6 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                 dlog[c] = c < a.C ? v : 0.0f;
             }
         }
-        auto stage_piece = [&](int c, int buf, int j) {
-            const int idx = wave + 4 * j;
-            const int gl = idx / NT, tt = idx % NT;
-            const float* src = a.wp + ((long)(c * G + gl) * ntile + nb * NT + tt) * 256 + lane * 4;
-            glds16(src, __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * CHUNK + idx * 256) * 4u));
-        };
         stage(0, 0);
         stage(nchunk > 1 ? 1 : 0, 1);
         float av[G][4];

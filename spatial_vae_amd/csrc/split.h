@@ -47,15 +47,6 @@ template <int OFF>
 __device__ __forceinline__ void load_frag_s(const void* sbase, unsigned voff, u32x4& v) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(v) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
 }
-// one 1 KiB LDS-DMA piece (see glds16 in dense.h), SGPR base + 32-bit per-lane byte offset
-__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
-        : "memory");
-}
 template <int N>
 __device__ __forceinline__ void wait_frag(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
