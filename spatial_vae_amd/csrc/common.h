@@ -181,6 +181,34 @@ __device__ __forceinline__ float half_sum_dpp_hi(float v) {
     return v;
 }
 
+// Sixteen values per lane, each to be summed over the 32 lanes of its half-wave: instead of 16 full butterflies (160
+// instructions) the lanes SPLIT the work -- after exchanging with lane^1 a lane carries only 8 of the 16 sums, after
+// lane^2 only 4; those 4 are then summed over the row's four quads (row_ror 4, 8) and over the two rows (lane^16).
+// 72 instructions.  On return out[0..3] are the complete sums for value indices 4*q + (0..3) with
+//   q = ((lane & 1) << 1) | ((lane >> 1) & 1)
+// i.e. the lanes 0..3 of a half-wave together hold all 16 results (every other lane holds a copy of its class).
+__device__ __forceinline__ void half_reduce16(const float (&v)[16], float (&out)[4]) {
+    const bool b0 = (threadIdx.x & 1) != 0, b1 = (threadIdx.x & 2) != 0;
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float keep = b0 ? v[j + 8] : v[j], send = b0 ? v[j] : v[j + 8];
+        w[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, true));  // lane ^ 1
+    }
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b1 ? w[j + 4] : w[j], send = b1 ? w[j] : w[j + 4];
+        x[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, true));  // lane ^ 2
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[j]), 0x124, 0xf, 0xf, true));  // row_ror 4
+        x[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[j]), 0x128, 0xf, 0xf, true));  // row_ror 8
+        out[j] = x[j] + __shfl_xor(x[j], 16);                                                                   // the other row
+    }
+}
+
 // sum over a 256-thread block; result valid in every thread.  red must hold 4 floats.
 __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum32(v);

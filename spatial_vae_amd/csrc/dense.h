@@ -442,18 +442,16 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                         if ((DGRAD || RESID) && t + 1 < NT) fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
                         finish(t, xa[t & 1], xr[t & 1]);
                     }
-                    if (CF > 0) {  // sum over this block's columns (the 32 lanes of each half-wave); lane nl == 31 stores
+                    if (CF > 0) {  // sum over this block's columns (the 32 lanes of each half-wave); lanes nl < 4 store
 #pragma unroll
-                        for (int c = 0; c < CFN; ++c)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) lp[c][r] = half_sum_dpp_hi(lp[c][r]);
-                        if (nl == 31) {
-#pragma unroll
-                            for (int c = 0; c < CFN; ++c)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)  // rows 8q + 4h .. +3 of the tile are consecutive
-                                    *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
-                                        make_float4(lp[c][4 * q], lp[c][4 * q + 1], lp[c][4 * q + 2], lp[c][4 * q + 3]);
+                        for (int c = 0; c < CFN; ++c) {
+                            float s4[4];
+                            half_reduce16(lp[c], s4);
+                            if (nl < 4) {  // lane class -> row quad q; rows 8q + 4h .. +3 of the tile are consecutive
+                                const int q = ((nl & 1) << 1) | (nl >> 1);
+                                *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
+                                    make_float4(s4[0], s4[1], s4[2], s4[3]);
+                            }
                         }
                     }
                 } else {
@@ -519,20 +517,18 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                         *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) = make_float4(g0, g1, sv, 0.0f);
                     }
                     // d(coords) of each row: sum this block's NB features = over the tiles (done) and the 32 lanes
-#pragma unroll
-                    for (int idx = 0; idx < 16; ++idx) {  // DPP only: result in lanes 16..31 of each half-wave
-                        pd0[idx] = half_sum_dpp_hi(pd0[idx]);
-                        pd1[idx] = half_sum_dpp_hi(pd1[idx]);
-                    }
-                    if (nl == 31) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                    {
+                        float s0[4], s1[4];
+                        half_reduce16(pd0, s0);
+                        half_reduce16(pd1, s1);
+                        if (nl < 4) {
+                            const int q = ((nl & 1) << 1) | (nl >> 1);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const long m = tl * 32 + 8 * q + 4 * h + r;
-                                *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) =
-                                    make_float2(pd0[4 * q + r], pd1[4 * q + r]);
+                                *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) = make_float2(s0[r], s1[r]);
                             }
+                        }
                     }
                 }
             };

@@ -517,19 +517,17 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
         }
         if (CF > 0) {
 #pragma unroll
-            for (int c = 0; c < CFN; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lp[c][r] = half_sum_dpp_hi(lp[c][r]);
-            if (nl == 31) {
-#pragma unroll
-                for (int c = 0; c < CFN; ++c)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
-                            make_float4(lp[c][4 * q], lp[c][4 * q + 1], lp[c][4 * q + 2], lp[c][4 * q + 3]);
+            for (int c = 0; c < CFN; ++c) {
+                float s4[4];
+                half_reduce16(lp[c], s4);
+                if (nl < 4) {
+                    const int q = ((nl & 1) << 1) | (nl >> 1);
+                    *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
+                        make_float4(s4[0], s4[1], s4[2], s4[3]);
+                }
             }
         }
-            } else {
+        } else {
         constexpr int NB = NT * 32;
         const float inv = (a.scale ? a.scale[1] : kActInv) * a.wscale[1];
         const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;
@@ -611,19 +609,18 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
                 }
                 *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) = make_float4(g0, g1, sv, 0.0f);
             }
-#pragma unroll
-            for (int idx = 0; idx < 16; ++idx) {
-                pd0[idx] = half_sum_dpp_hi(pd0[idx]);
-                pd1[idx] = half_sum_dpp_hi(pd1[idx]);
-            }
-            if (nl == 31) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
+            {
+                float s0[4], s1[4];
+                half_reduce16(pd0, s0);
+                half_reduce16(pd1, s1);
+                if (nl < 4) {
+                    const int q = ((nl & 1) << 1) | (nl >> 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const long m = tl * 32 + 8 * q + 4 * h + r;
-                        *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) = make_float2(pd0[4 * q + r], pd1[4 * q + r]);
+                        *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) = make_float2(s0[r], s1[r]);
                     }
+                }
             }
         }
         }
