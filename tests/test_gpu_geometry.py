@@ -31,6 +31,12 @@ GEOMS = [
     dict(name="one_layer_wide", n=8, m=8, B=4, H=300, L=1),
     dict(name="particles_noise_mask_resid", script="particles", n=8, m=8, B=5, H=70, L=3, n_out=2, mask=True, resid=True,
          act="leakyrelu", z_scale=0.3),
+    # widths that are multiples of 64 with bounded activations: the shapes the fp16x3 GEMM mode takes (tests/test_gpu_split.py
+    # runs this file with the mode on) -- residual stack, two-channel fused logits, sigmoid chain, 8-tile width
+    dict(name="w64_resid_tanh_deep", n=6, m=6, B=3, H=64, L=4, resid=True),
+    dict(name="w128_two_channels_noise", script="particles", n=8, m=8, B=4, H=100, L=2, n_out=2),
+    dict(name="w128_sigmoid_three", n=5, m=7, B=3, H=128, L=3, act="sigmoid", z_dim=3),
+    dict(name="w256_rgb_two_layers", script="galaxy", n=6, m=6, B=3, H=250, L=2, n_out=3, z_dim=5),
 ]
 
 
