@@ -896,6 +896,21 @@ int svae_gaussian_loglik(int32_t B, int32_t N, int32_t C, const float* y_params,
         dflt = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
     }
     Scope prof(K_GAUSSIAN, static_cast<hipStream_t>(stream));
+    if (ctf) {  // the correlation and its adjoint out of LDS when the padded image and the filter fit (they do up to ~100 x 100)
+        const int n = (int)(sqrt((double)N) + 0.5);
+        const CtfLds cg = CtfLds::make(n, k);
+        const size_t lds = ((size_t)cg.W * cg.Wp + (size_t)k * cg.kp) * sizeof(float);
+        static const bool lds_env = [] { const char* e = getenv("SVAE_CTF_LDS"); return !(e && e[0] == '0'); }();
+        if (lds_env && lds <= 150 * 1024) {
+            if (lds > 48 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gaussian_ctf_lds_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(SVAE_E_LAUNCH, "svae_gaussian_loglik: cannot reserve %zu bytes of LDS", lds);
+            hipLaunchKernelGGL(gaussian_ctf_lds_kernel, dim3(B), dim3(kCtfThreads), lds, static_cast<hipStream_t>(stream),
+                               y_params, target, mask, ctf, k, loglik, dll_dy, filt, dflt, N);
+            return launch_status("svae_gaussian_loglik");
+        }
+    }
     hipLaunchKernelGGL(gaussian_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), y_params, target, mask, ctf,
                        k, loglik, dll_dy, filt, dflt, N, C);
     return launch_status("svae_gaussian_loglik");

@@ -3,6 +3,7 @@
 // gradient reductions of A8.  All reductions are fixed-order (no atomics): results are bitwise
 // reproducible run to run.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace svae {
@@ -619,6 +620,114 @@ __global__ void gaussian_kernel(const float* __restrict__ yp, const float* __res
             }
             dll[(long)b * N * C + j] = s;
         }
+    }
+}
+
+// The same with the CTF cross-correlation and its adjoint running out of LDS: the zero-padded image
+// ((n + k - 1)^2 floats; 78 x 78 for 40 x 40 particles with a 39 x 39 filter) and the filter (rows zero-padded to a
+// multiple of 4 taps) sit in LDS; a thread produces 4 consecutive outputs of a row, 4 taps at a time, from two 16-byte
+// reads of the image row and one (broadcast) of the filter row per 16 multiply-adds, no bounds tests.  Every output
+// still accumulates its taps in the reference's (u, v) order and the padding only adds exact zeros, so results equal
+// gaussian_kernel's bit for bit.  512 threads: the 400 (row, column group) tasks of a 40 x 40 image run in one round.
+constexpr int kCtfThreads = 512;
+struct CtfLds {
+    int W, Wp, kp, M;  // padded side, its row stride, padded filter row, left margin of the adjoint's image
+    __host__ __device__ static CtfLds make(int n, int k) {
+        CtfLds g;
+        const int pad = k / 2;
+        g.W = n + 2 * pad;
+        g.kp = (k + 3) & ~3;
+        g.M = 3 + ((4 - ((2 * pad) & 3)) & 3);     // >= 3 and (2 pad - 3 + M) % 4 == 0
+        g.Wp = ((g.W + g.M + 3) & ~3) + 8;          // room for the margin and for reads past the last tap
+        return g;
+    }
+};
+__global__ void __launch_bounds__(kCtfThreads) gaussian_ctf_lds_kernel(const float* __restrict__ yp,
+                                                                        const float* __restrict__ target,
+                                                                        const uint8_t* __restrict__ mask,
+                                                                        const float* __restrict__ ctf, int k,
+                                                                        float* __restrict__ loglik, float* __restrict__ dll,
+                                                                        float* __restrict__ filt, float* __restrict__ dflt,
+                                                                        int N) {
+    extern __shared__ __attribute__((aligned(16))) float ctf_lds[];
+    __shared__ float red[kCtfThreads / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = (int)(sqrtf((float)N) + 0.5f);
+    const CtfLds g = CtfLds::make(n, k);
+    const int pad = k / 2, W = g.W, Wp = g.Wp, kp = g.kp;
+    float* P = ctf_lds;            // W rows x Wp
+    float* F = ctf_lds + W * Wp;   // k rows x kp
+    const float* row = yp + (long)b * N;  // C == 1 with a CTF (checked by the caller)
+    const float* f = ctf + (long)b * k * k;
+    // image at column offset 0 (forward) or M (adjoint); everything else zero
+    auto stage = [&](const float* src, int margin) {
+        for (int i = tid; i < W * Wp; i += kCtfThreads) {
+            const int r = i / Wp - pad, c = i % Wp - margin - pad;
+            P[i] = (r >= 0 && r < n && c >= 0 && c < n) ? src[r * n + c] : 0.0f;
+        }
+    };
+    stage(row, 0);
+    for (int i = tid; i < k * kp; i += kCtfThreads) {
+        const int u = i / kp, v = i % kp;
+        F[i] = v < k ? f[u * k + v] : 0.0f;
+    }
+    __syncthreads();
+    const int groups = (n + 3) / 4;
+    auto pass = [&](auto flip_tag, float* out) {
+        constexpr bool flip = decltype(flip_tag)::value;
+        for (int t = tid; t < n * groups; t += kCtfThreads) {
+            const int r = t / groups, c0 = (t % groups) * 4;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int u = 0; u < k; ++u) {
+                const float* prow = P + (r + (flip ? 2 * pad - u : u)) * Wp;
+                const float* frow = F + u * kp;
+                for (int v0 = 0; v0 < kp; v0 += 4) {
+                    // forward: output i, tap v0+j reads column c0 + i + v0 + j           = s + i + j,     s = c0 + v0
+                    // adjoint: output i, tap v0+j reads column c0 + i + 2 pad - v0 - j + M = s + 3 + i - j, s = c0 + 2 pad - v0 - 3 + M
+                    const int s0 = flip ? c0 + 2 * pad - v0 - 3 + g.M : c0 + v0;
+                    const float4 pa = *reinterpret_cast<const float4*>(prow + s0);
+                    const float4 pb = *reinterpret_cast<const float4*>(prow + s0 + 4);
+                    const float4 fv = *reinterpret_cast<const float4*>(frow + v0);
+                    const float pw[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+                    const float ff[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] += (flip ? pw[3 + i - j] : pw[i + j]) * ff[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c0 + i < n) out[r * n + c0 + i] = acc[i];
+        }
+    };
+    pass(std::false_type(), filt + (long)b * N);
+    __syncthreads();
+    float acc = 0.0f;
+    for (int j = tid; j < N; j += kCtfThreads) {
+        const bool on = mask ? mask[j] != 0 : true;
+        const float diff = filt[(long)b * N + j] - target[(long)b * N + j];
+        float dmu = 0.0f;
+        if (on) {
+            acc += -0.5f * diff * diff;
+            dmu = -diff;
+        }
+        if (dll) dflt[(long)b * N + j] = dmu;
+    }
+    acc = wave_sum32(acc);
+    acc += __shfl_xor(acc, 32);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.0f;
+        for (int i = 0; i < kCtfThreads / 64; ++i) t += red[i];
+        loglik[b] = t;
+    }
+    if (dll) {
+        __syncthreads();
+        stage(dflt + (long)b * N, g.M);
+        __syncthreads();
+        pass(std::true_type(), dll + (long)b * N);
     }
 }
 
