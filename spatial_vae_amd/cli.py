@@ -182,6 +182,9 @@ def train_main(script, args, build):
     p_net, q_net, rotate, translate, table)."""
     rank, world, _ = dp.init_process_group(device_is_gpu=True)
     device = pick_device(args.device)
+    if getattr(args, "gemm", None):                 # before the first decoder call: buffer sizes depend on the mode
+        from . import _lib
+        _lib.set_gemm_mode(args.gemm)
     start = time.time()
     prefix = args.save_prefix
     out_dir = trained = None

@@ -82,3 +82,16 @@ def test_train_particles_reads_mrcs_stacks(tmp_path):
     rows = _run("train_particles.py", ["tr.mrcs", "te.mrcs", "--num-epochs", "1", "--minibatch-size", "32", "--p-hidden-dim", "32",
                                        "--q-hidden-dim", "32", "--crop", "20", "--normalize", "--progress-every", "0"], str(tmp_path))
     assert len(rows) == 3 and all(np.isfinite([float(v) for v in r.split("\t")[2:]]).all() for r in rows[1:])
+
+
+def test_gemm_flag_selects_the_split_operand_path(tmp_path):
+    """--gemm fp16x3 (an addition to the reference's flags): same training tables, same convergence on the synthetic set."""
+    common = ["--synthetic", "512", "--num_epochs", "2", "--minibatch_size", "64", "--p_hidden_dim", "64", "--q_hidden_dim", "32",
+              "--progress_every", "0", "--save_interval", "100"]
+    a = _run("train_mnist.py", common + ["--save_prefix", "a"], str(tmp_path))
+    b = _run("train_mnist.py", common + ["--save_prefix", "b", "--gemm", "fp16x3"], str(tmp_path))
+    va = [[float(x) for x in r.split("\t")] for r in a[1:]]
+    vb = [[float(x) for x in r.split("\t")] for r in b[1:]]
+    assert len(va) == len(vb) == 4
+    for ra, rb in zip(va, vb):                       # different noise draws per run: compare the level, not the digits
+        assert abs(ra[1] - rb[1]) < 0.05 * abs(ra[1])
