@@ -17,8 +17,9 @@ published algorithm is restated here:
     evaluated in Horner form (coefficients in the C type of the samples, see _cubic), 8-bit output clamped to
     [0, 255] and truncated ((UINT8) cast; that is what Pillow 12.2.0 does -- verified sample by sample).
 
-Pinned against Pillow itself (tests/test_oracle_rotate.py runs both where PIL is importable) and by the fixtures
-tests/golden/rotate_golden.npz, which tests/golden/gen_rotate_golden.py wrote by calling Pillow.
+Pinned against Pillow itself (tests/test_oracle_rotate.py runs both where PIL is importable) and by the `y_rot` entries of
+tests/golden/galaxy_augment.npz / particles_augment.npz: the rotated batches the REFERENCE's eval_minibatch fed its encoder,
+captured by tests/golden/gen_golden.py (which runs the reference, and through it Pillow, on the seeded cases).
 """
 import math
 
