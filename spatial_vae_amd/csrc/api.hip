@@ -526,7 +526,10 @@ template <bool DGRAD>
 void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
     const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
-    const dim3 grid((unsigned)((g.tiles + 3) / 4), (unsigned)(g.ntile / nt));
+    static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
+    const long groups = (g.tiles + 3) / 4;
+    const dim3 grid = (xcd_grid && g.ntile / nt > 1) ? dim3((unsigned)(((groups + 7) / 8) * 8 * (g.ntile / nt)))
+                                                     : dim3((unsigned)groups, (unsigned)(g.ntile / nt));
     switch (nt) {
         case 16: launch_dense_nt<16, DGRAD>(a, grid, st, first, lastd, cf); break;
         case 8: launch_dense_nt<8, DGRAD>(a, grid, st, first, lastd, cf); break;

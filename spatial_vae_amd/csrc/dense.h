@@ -201,12 +201,26 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nl = lane & 31, h = lane >> 5;
-    const long tile = (long)blockIdx.x * 4 + wave;
-    const bool live = tile < a.tiles;
-    const long tl = live ? tile : a.tiles - 1;  // dead waves recompute the last tile and store nothing
     const int Hp = a.Hp;
     const int noct = Hp / 8;       // multiple of 4
     const int nchunk = noct / G;
+    // XCD-aware 1-D grid (gridDim.y == 1): workgroup ids congruent mod 8 share an XCD and its L2; the column blocks of one
+    // 128-row group get consecutive ids on ONE XCD, so the group's row operand comes from HBM once instead of once per
+    // column block.  (The kernel is MFMA-bound either way; this trims HBM traffic and power.)  Legacy 2-D grid otherwise.
+    long grp;
+    int nb_;
+    if (gridDim.y == 1) {
+        const int nblk = (Hp / 32) / NT;
+        const long local = blockIdx.x >> 3;
+        nb_ = (int)(local % nblk);
+        grp = (local / nblk) * 8 + (blockIdx.x & 7);
+    } else {
+        nb_ = blockIdx.y;
+        grp = blockIdx.x;
+    }
+    const long tile = grp * 4 + wave;
+    const bool live = tile < a.tiles;
+    const long tl = live ? tile : a.tiles - 1;  // dead waves recompute the last tile and store nothing
 
     // this lane's row (m = nl) of the row operand: element (m, k) at ((m>>3)*Hp + k)*8 + (m&7)
     const float* arow = a.in + ((((SVAE_ABLATE & 32) ? 0 : tl) * 4 + (nl >> 3)) * (long)Hp + 4 * h) * 8 + (nl & 7);
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
     // 32 rows x NB columns (not x Hp) gives the dispatcher twice as many, half as long workgroups to
     // balance over the 256 CUs x 2 resident workgroups (6.25 rounds instead of 3.1 at BASELINE cfg 2).
     {
-        const int nb = blockIdx.y;
+        const int nb = nb_;
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
