@@ -788,7 +788,12 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                 launch_split_wgrad(g, pl, pl.dh[cur], pl.act[l - 1],
                                    (l == 1 && g.L == 2 && split_l0_on()) ? pl.savedC : (const uint4*)nullptr,
                                    split_ob && l == g.L - 1, st);
-            else launch_wgrad(w, dim3(pl.wg_nblk1 * pl.wg_nblk1, pl.wg_S), last ? g.C : 0, st);
+            else {
+                static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
+                const int nb2 = pl.wg_nblk1 * pl.wg_nblk1;
+                w.S = (xcd_grid && nb2 > 1 && pl.wg_S % 8 == 0) ? pl.wg_S : 0;
+                launch_wgrad(w, w.S ? dim3(nb2 * pl.wg_S) : dim3(nb2, pl.wg_S), last ? g.C : 0, st);
+            }
             Scope prof(K_WGRAD_REDUCE, st);
             const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,

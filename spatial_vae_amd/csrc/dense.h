@@ -580,6 +580,7 @@ struct WgradArgs {
     long noct;
     int Hp;
     int nblk1;           // blocks per side = ceil(ntile / 8)
+    int S;               // > 0: 1-D XCD-aware grid of nblk1^2 * S workgroups; 0: 2-D grid (blocks, splits)
 };
 
 constexpr int kWgradLdsBytes = 4 * 4 * 9 * 1024;  // 4 waves x 4 ring slots x (8 operand pieces + 1 d(logits) piece) KiB
@@ -597,11 +598,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nl = lane & 31, h = lane >> 5;
     const int Hp = a.Hp, ntile = Hp / 32;
-    const int bi = blockIdx.x / a.nblk1, bj = blockIdx.x % a.nblk1;
+    // grid: (blocks of dW, row-range splits), or 1-D and XCD-aware when a.S > 0 (then S % 8 == 0): the blocks of one split
+    // read the same rows of both operands and get workgroup ids congruent mod 8 -- one XCD, one L2
+    int blk, split;
+    long S;
+    if (a.S > 0) {
+        const int nb2 = a.nblk1 * a.nblk1, local = blockIdx.x >> 3;
+        S = a.S;
+        blk = local % nb2;
+        split = (local / nb2) * 8 + (blockIdx.x & 7);
+    } else {
+        S = gridDim.y;
+        blk = blockIdx.x;
+        split = blockIdx.y;
+    }
+    const int bi = blk / a.nblk1, bj = blk % a.nblk1;
     const int ibase = bi * 8 + (wave >> 1) * 4, jbase = bj * 8 + (wave & 1) * 4;
-    const long S = gridDim.y;
     const long per = (a.noct + S - 1) / S;
-    const long o0 = blockIdx.y * per;
+    const long o0 = split * per;
     const long o1 = (o0 + per < a.noct) ? o0 + per : a.noct;
 
     const float* pa[4];
@@ -747,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         dma_wait_all();  // the clamped pieces still in flight (they only ever target this wave's ring)
     }
 
-    float* slab = a.slab + (long)blockIdx.y * Hp * Hp;
+    float* slab = a.slab + (long)split * Hp * Hp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (ibase + i >= ntile) continue;
@@ -767,14 +781,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         for (int c = 0; c < CL; ++c) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (ibase + i < ntile) a.wpart[(((long)blockIdx.y * 2 + h) * CL + c) * Hp + (ibase + i) * 32 + nl] = pw[c][i];
-            if (bi == 0 && wave == 0 && nl == 0) a.bpart[((long)blockIdx.y * 2 + h) * CL + c] = pbias[c];
+                if (ibase + i < ntile) a.wpart[(((long)split * 2 + h) * CL + c) * Hp + (ibase + i) * 32 + nl] = pw[c][i];
+            if (bi == 0 && wave == 0 && nl == 0) a.bpart[((long)split * 2 + h) * CL + c] = pbias[c];
         }
     }
     if (bj == 0 && (wave & 1) == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (ibase + i < ntile) a.bslab[((long)blockIdx.y * 2 + h) * Hp + (ibase + i) * 32 + nl] = bs[i];
+            if (ibase + i < ntile) a.bslab[((long)split * 2 + h) * Hp + (ibase + i) * 32 + nl] = bs[i];
     }
 }
 
