@@ -279,7 +279,7 @@ struct SplitArgs {
 };
 
 // timing-only ablation switches (never set in the product build): 1 = every tile reads the rows of tile 0 (L2-hot row
-// operand), 2 = no result stores, 4 = no weight DMA / barrier in the loop, 8 = no weight-fragment LDS reads in the loop
+// operand), 2 = no result stores, 4 = no weight DMA / barrier in the loop, 8 = no weight-fragment LDS reads in the loop, 128 = no data-gradient epilogue
 #ifndef SVAE_SPLIT_ABLATE
 #define SVAE_SPLIT_ABLATE 0
 #endif
@@ -300,6 +300,9 @@ struct SplitCfg {
 // kSplitWaves waves (row tiles) share the weight chunks: at f16-MFMA speed the vector-memory path (64 B/clk/CU) is the
 // scarce resource -- every wave streams 2 KiB of row fragments per K-step and its share of the 2 KiB x NT weight blocks;
 // eight waves per workgroup instead of four halve the weight share (ablation: the LDS-DMA alone cost 0.09 of 0.32 ms).
+#ifndef SVAE_SPLIT_BD2
+#define SVAE_SPLIT_BD2 2  // weight-fragment read-ahead (column tiles) of the fused first-layer variant, which has registers to spare
+#endif
 #ifndef SVAE_SPLIT_WAVES
 #define SVAE_SPLIT_WAVES 8
 #endif
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
                 for (int j = 0; j < P; ++j) asm volatile("s_nop 0" ::: "memory");
             }
             // weight fragments are read kBD column tiles ahead of the MFMAs that use them (a ring of kBD + 1 register pairs)
-            constexpr int kBD = 2, kBR = kBD + 1;
+            constexpr int kBD = (MODE == 2) ? SVAE_SPLIT_BD2 : 2, kBR = kBD + 1;
             Frag bq[kBR][2];
 #pragma unroll
             for (int i = 0; i < kBD; ++i) {
@@ -527,6 +530,8 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
                 }
             }
         }
+        } else if ((SVAE_SPLIT_ABLATE & 128) && a.tiles >= 0) {
+            // ablation: no data-gradient epilogue (a.tiles >= 0 is always true; the else branch keeps the code alive)
         } else {
         constexpr int NB = NT * 32;
         const float inv = (a.scale ? a.scale[1] : kActInv) * a.wscale[1];
