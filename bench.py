@@ -201,8 +201,8 @@ def main():
     pool = [torch.from_numpy(synthetic_batch(rs, cfg["B"], N)).to(dev) for _ in range(4)]
 
     def run(k):
-        for i in range(k):
-            step(x, pool[i % len(pool)])
+        for i in range(k):  # each rank holds 1/world of the global minibatch: its mean gradient enters the all-reduce with that weight
+            step(x, pool[i % len(pool)], weight=1.0 / world)
 
     if args.graph:
         if world > 1:
