@@ -196,6 +196,15 @@ int svae_latent_backward(const svae_latent_desc* d, const float* q_out, const fl
                          svae_stream_t stream);
 
 /*
+ * The three scalars eval_minibatch returns, from the per-image terms: out3 = {elbo, log_p_x_g_z, kl_div} =
+ * {mean(loglik) - mean(kl), mean(loglik), mean(kl)} (train_mnist.py:81, 86-88: `kl_div.mean()`, `elbo = log_p - kl_div`),
+ * and the gradient of any combination of them back to the per-image terms.  g_* are device scalars or null.
+ */
+int svae_elbo_head_forward(const float* loglik, const float* kl, int32_t B, float* out3, svae_stream_t stream);
+int svae_elbo_head_backward(const float* g_elbo, const float* g_logp, const float* g_kl, int32_t B, float* dloglik, float* dkl,
+                            svae_stream_t stream);
+
+/*
  * One Adam update over a flat fp32 parameter buffer: the arithmetic of torch.optim.Adam (amsgrad off, no weight
  * decay) as the reference uses it (optim = torch.optim.Adam(params, lr=lr); optim.step(), train_mnist.py:389,
  * 149), element-wise:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;

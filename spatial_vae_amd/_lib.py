@@ -82,6 +82,10 @@ def lib():
     L.svae_latent_forward.argtypes = [ctypes.POINTER(LatentDesc), vp, vp, vp, vp, vp, vp, vp]
     L.svae_latent_backward.restype = ctypes.c_int
     L.svae_latent_backward.argtypes = [ctypes.POINTER(LatentDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    L.svae_elbo_head_forward.restype = ctypes.c_int
+    L.svae_elbo_head_forward.argtypes = [vp, vp, i32, vp, vp]
+    L.svae_elbo_head_backward.restype = ctypes.c_int
+    L.svae_elbo_head_backward.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     L.svae_adam_step.restype = ctypes.c_int
     L.svae_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_int64, vp]

@@ -960,6 +960,23 @@ int svae_latent_backward(const svae_latent_desc* d, const float* q_out, const fl
     return launch_status("svae_latent_backward");
 }
 
+int svae_elbo_head_forward(const float* loglik, const float* kl, int32_t B, float* out3, svae_stream_t stream) {
+    if (!loglik || !kl || !out3 || B < 1) return fail(SVAE_E_INVALID, "svae_elbo_head_forward: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_LATENT, st);
+    hipLaunchKernelGGL(elbo_head_fwd_kernel, dim3(1), dim3(256), 0, st, loglik, kl, B, out3);
+    return launch_status("svae_elbo_head_forward");
+}
+
+int svae_elbo_head_backward(const float* g_elbo, const float* g_logp, const float* g_kl, int32_t B, float* dloglik, float* dkl,
+                            svae_stream_t stream) {
+    if (!dloglik || !dkl || B < 1) return fail(SVAE_E_INVALID, "svae_elbo_head_backward: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_LATENT, st);
+    hipLaunchKernelGGL(elbo_head_bwd_kernel, dim3(blocks_for(B)), dim3(256), 0, st, g_elbo, g_logp, g_kl, B, dloglik, dkl);
+    return launch_status("svae_elbo_head_backward");
+}
+
 int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, int64_t step, svae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return fail(SVAE_E_INVALID, "svae_adam_step: bad arguments");

@@ -731,6 +731,35 @@ __global__ void __launch_bounds__(kCtfThreads) gaussian_ctf_lds_kernel(const flo
     }
 }
 
+// ---------------------------------------------------------------- A7: the three scalars of a minibatch and their backward
+// out = {elbo, log_p, kl} = {mean(loglik) - mean(kl), mean(loglik), mean(kl)}  (train_mnist.py:81, 86-88); one block,
+// fixed summation order.  Replaces four tiny torch kernels forward and five backward.
+__global__ void elbo_head_fwd_kernel(const float* __restrict__ loglik, const float* __restrict__ kl, int B, float* __restrict__ out) {
+    __shared__ float red[4];
+    float a = 0.0f, b = 0.0f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        a += loglik[i];
+        b += kl[i];
+    }
+    a = block_sum256(a, red);
+    b = block_sum256(b, red);
+    if (threadIdx.x == 0) {
+        const float lp = a / (float)B, k = b / (float)B;
+        out[0] = lp - k;
+        out[1] = lp;
+        out[2] = k;
+    }
+}
+// d/d loglik[b] = (g_elbo + g_logp) / B, d/d kl[b] = (g_kl - g_elbo) / B; absent upstream gradients are null
+__global__ void elbo_head_bwd_kernel(const float* __restrict__ g_elbo, const float* __restrict__ g_logp,
+                                     const float* __restrict__ g_kl, int B, float* __restrict__ dloglik, float* __restrict__ dkl) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float ge = g_elbo ? g_elbo[0] : 0.0f, gl = g_logp ? g_logp[0] : 0.0f, gk = g_kl ? g_kl[0] : 0.0f;
+    dloglik[i] = (ge + gl) / (float)B;
+    dkl[i] = (gk - ge) / (float)B;
+}
+
 // ---------------------------------------------------------------- A7: latent head (reparameterise, split, KL)
 struct LatentGeo {
     int B, inf, rotate, translate, mu_penalty;

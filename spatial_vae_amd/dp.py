@@ -113,9 +113,21 @@ class TrainStep(object):
         params = list(p_net.parameters()) + list(q_net.parameters())
         on_gpu = params[0].is_cuda
         sink_params = p_net.decoder_parameters() if (on_gpu and hasattr(p_net, "decoder_parameters")) else None
+        q_sinks = {}
+        if on_gpu and sink_params is not None and hasattr(q_net, "layers"):
+            # the encoder's plain Linear layers: elbo._encode runs them through ops.sink_linear, whose backward writes the
+            # weight / bias gradients into the flat buffer directly (no AccumulateGrad add per parameter)
+            for idx, m in enumerate(q_net.layers):
+                if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                    q_sinks["layers.%d.weight" % idx] = m.weight
+                    q_sinks["layers.%d.bias" % idx] = m.bias
+            sink_params = dict(sink_params, **q_sinks)
         self.grads = FlatGrads(params, sink_params=sink_params, flatten_params=True)
         if sink_params:
-            p_net._grad_sinks = self.grads.sinks
+            p_net._grad_sinks = {k: v for k, v in self.grads.sinks.items() if k not in q_sinks}
+            if q_sinks:
+                q_net._grad_sinks = {k: v for k, v in self.grads.sinks.items() if k in q_sinks}
+        self._minus_one = torch.tensor(-1.0, device=params[0].device)
         self.master = torch.nn.Parameter(self.grads.flat_param)
         self.master.grad = self.grads.flat
         if on_gpu and fused_adam is None:
@@ -131,7 +143,7 @@ class TrainStep(object):
         args.update(kw)
         out = self.eval_minibatch(x, *batch, self.p_net, self.q_net, **args)
         elbo = out[0]
-        (-elbo).backward()
+        elbo.backward(self._minus_one)                  # loss = -elbo (train_mnist.py:147-148) without a negation kernel
         self.grads.all_reduce(weight)
         self.optim.step()
         self.grads.zero()

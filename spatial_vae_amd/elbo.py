@@ -18,6 +18,7 @@ import math
 
 import numpy as np
 import torch
+import torch.nn as nn
 
 from . import ops
 
@@ -26,6 +27,16 @@ def _encode(q_net, y2d):
     """Raw encoder output [z_mu | z_logstd] (B, 2*inf_dim): InferenceNetwork.forward is layers(x) split in two
     (models.py:46-54); any other encoder's two outputs are concatenated back."""
     if hasattr(q_net, "layers") and hasattr(q_net, "latent_dim"):
+        sinks = getattr(q_net, "_grad_sinks", None)     # set by dp.TrainStep: gradient views into its flat buffer
+        if sinks and torch.is_grad_enabled():
+            h = y2d
+            for idx, m in enumerate(q_net.layers):
+                key = "layers.%d.weight" % idx
+                if isinstance(m, nn.Linear) and key in sinks:
+                    h = ops.sink_linear(h, m.weight, m.bias, sinks[key], sinks["layers.%d.bias" % idx])
+                else:
+                    h = m(h)
+            return h
         return q_net.layers(y2d)
     z_mu, z_logstd = q_net(y2d)
     return torch.cat([z_mu, z_logstd], 1)
@@ -74,9 +85,7 @@ def _core(script, x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior, 
         loglik = ops.gaussian_loglik(y_hat.reshape(B, -1), y.view(B, -1), mask=mask, ctf=ctf)
     else:
         loglik = ops.bce_loglik(y_hat.reshape(B, -1), y.reshape(B, -1))
-    log_p_x_g_z = loglik.mean()
-    kl_div = kl_b.mean()
-    elbo = log_p_x_g_z - kl_div
+    elbo, log_p_x_g_z, kl_div = ops.elbo_head(loglik, kl_b)     # the two batch means and their difference, one kernel
     return elbo, log_p_x_g_z, kl_div, y_hat, logits
 
 

@@ -224,6 +224,66 @@ def latent_head(q_out, r, rotate, translate, mu_penalty, dx_scale, z_scale, thet
     return _Latent.apply(q_out, r, rotate, translate, mu_penalty, dx_scale, z_scale, theta_prior)
 
 
+class _ElboHead(torch.autograd.Function):
+    """elbo, log_p, kl = mean(loglik) - mean(kl_b), mean(loglik), mean(kl_b)  (svae_elbo_head_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, loglik, kl_b):
+        L = _lib.lib()
+        _require_hip(loglik, "loglik")
+        loglik, kl_b = _f32(loglik), _f32(kl_b)
+        B = loglik.numel()
+        if kl_b.numel() != B:
+            raise RuntimeError("loglik has %d entries, kl %d" % (B, kl_b.numel()))
+        out = torch.empty(3, dtype=torch.float32, device=loglik.device)
+        with torch.cuda.device(loglik.device):
+            _lib.check(L.svae_elbo_head_forward(loglik.data_ptr(), kl_b.data_ptr(), B, out.data_ptr(), _stream(loglik.device)))
+        ctx.B, ctx.shapes = B, (loglik.shape, kl_b.shape)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_logp, g_kl):
+        L = _lib.lib()
+        ref = next(g for g in (g_elbo, g_logp, g_kl) if g is not None)
+        g_elbo, g_logp, g_kl = _f32(g_elbo), _f32(g_logp), _f32(g_kl)
+        dl = torch.empty(ctx.B, dtype=torch.float32, device=ref.device)
+        dk = torch.empty(ctx.B, dtype=torch.float32, device=ref.device)
+        with torch.cuda.device(ref.device):
+            _lib.check(L.svae_elbo_head_backward(_p(g_elbo), _p(g_logp), _p(g_kl), ctx.B, dl.data_ptr(), dk.data_ptr(),
+                                                 _stream(ref.device)))
+        return dl.view(ctx.shapes[0]), dk.view(ctx.shapes[1])
+
+
+def elbo_head(loglik, kl_b):
+    """(elbo, log_p_x_g_z, kl_div) of a minibatch from its per-image log-likelihoods and KL terms."""
+    return _ElboHead.apply(loglik, kl_b)
+
+
+class _SinkLinear(torch.autograd.Function):
+    """y = x W^T + b; the backward pass writes dW and db straight into caller-owned gradient views (slices of the flat
+    buffer of dp.FlatGrads) with torch.mm(out=) / torch.sum(out=) instead of returning tensors that autograd would then
+    ADD into those views: one kernel less per parameter per step.  The arithmetic is torch's (hipBLASLt)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sink_w, sink_b):
+        ctx.save_for_backward(x, weight)
+        ctx.sinks = (sink_w, sink_b)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        sink_w, sink_b = ctx.sinks
+        dx = dy.mm(weight) if ctx.needs_input_grad[0] else None
+        torch.mm(dy.t(), x, out=sink_w)
+        torch.sum(dy, 0, out=sink_b)
+        return dx, None, None, None, None
+
+
+def sink_linear(x, weight, bias, sink_w, sink_b):
+    return _SinkLinear.apply(x, weight, bias, sink_w, sink_b)
+
+
 class _BceLoglik(torch.autograd.Function):
     """loglik[b] = -sum_j bce(y_hat[b, j], target[b, j])  (svae_bce_loglik)."""
 
