@@ -205,6 +205,12 @@ int svae_elbo_head_backward(const float* g_elbo, const float* g_logp, const floa
                             svae_stream_t stream);
 
 /*
+ * out[c] = sum_r x[r][c] for a row-major (rows, cols) fp32 matrix, fixed summation order: the bias gradient of a Linear
+ * layer (the encoder's, whose weight gradients torch computes with hipBLASLt).
+ */
+int svae_colsum(const float* x, int32_t rows, int32_t cols, float* out, svae_stream_t stream);
+
+/*
  * One Adam update over a flat fp32 parameter buffer: the arithmetic of torch.optim.Adam (amsgrad off, no weight
  * decay) as the reference uses it (optim = torch.optim.Adam(params, lr=lr); optim.step(), train_mnist.py:389,
  * 149), element-wise:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;

@@ -86,6 +86,8 @@ def lib():
     L.svae_elbo_head_forward.argtypes = [vp, vp, i32, vp, vp]
     L.svae_elbo_head_backward.restype = ctypes.c_int
     L.svae_elbo_head_backward.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.svae_colsum.restype = ctypes.c_int
+    L.svae_colsum.argtypes = [vp, i32, i32, vp, vp]
     L.svae_adam_step.restype = ctypes.c_int
     L.svae_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_int64, vp]

@@ -977,6 +977,14 @@ int svae_elbo_head_backward(const float* g_elbo, const float* g_logp, const floa
     return launch_status("svae_elbo_head_backward");
 }
 
+int svae_colsum(const float* x, int32_t rows, int32_t cols, float* out, svae_stream_t stream) {
+    if (!x || !out || rows < 1 || cols < 1) return fail(SVAE_E_INVALID, "svae_colsum: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_SMALL_BWD, st);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, st, x, out, cols, cols, rows);
+    return launch_status("svae_colsum");
+}
+
 int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, int64_t step, svae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return fail(SVAE_E_INVALID, "svae_adam_step: bad arguments");

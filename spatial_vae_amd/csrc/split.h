@@ -728,7 +728,8 @@ __global__ void colsum_reduce_kernel(const float* __restrict__ hbpart, float* __
     const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + col;
     float s = 0.0f;
-    for (int i = pl; i < nparts; i += 8) s += hbpart[(long)i * Hp + n];
+    if (n < Hp)  // Hp is the row stride; callers with unpadded rows (svae_colsum) have columns past it in the last block
+        for (int i = pl; i < nparts; i += 8) s += hbpart[(long)i * Hp + n];
     red[pl][col] = s;
     __syncthreads();
     if (pl == 0 && n < H) {

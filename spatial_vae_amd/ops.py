@@ -235,6 +235,7 @@ class _ElboHead(torch.autograd.Function):
         B = loglik.numel()
         if kl_b.numel() != B:
             raise RuntimeError("loglik has %d entries, kl %d" % (B, kl_b.numel()))
+        ctx.set_materialize_grads(False)     # unused outputs (log_p, kl) arrive as None, not as zero tensors autograd fills
         out = torch.empty(3, dtype=torch.float32, device=loglik.device)
         with torch.cuda.device(loglik.device):
             _lib.check(L.svae_elbo_head_forward(loglik.data_ptr(), kl_b.data_ptr(), B, out.data_ptr(), _stream(loglik.device)))
@@ -276,7 +277,11 @@ class _SinkLinear(torch.autograd.Function):
         sink_w, sink_b = ctx.sinks
         dx = dy.mm(weight) if ctx.needs_input_grad[0] else None
         torch.mm(dy.t(), x, out=sink_w)
-        torch.sum(dy, 0, out=sink_b)
+        if dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and sink_b.is_contiguous():
+            with torch.cuda.device(dy.device):   # column sums in ~3 us (ATen's reduce kernel takes 13 us for 256 x 500)
+                _lib.check(_lib.lib().svae_colsum(dy.data_ptr(), dy.size(0), dy.size(1), sink_b.data_ptr(), _stream(dy.device)))
+        else:
+            torch.sum(dy, 0, out=sink_b)
         return dx, None, None, None, None
 
 
