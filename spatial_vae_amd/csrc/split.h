@@ -537,9 +537,12 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
         const float inv = (a.scale ? a.scale[1] : kActInv) * a.wscale[1];
         const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;
         const long qstride = (long)Hp * 8;
+        // MODE 2 without a residual defers the 1/(s_a s_w) factor to its (few) sums instead of paying it per element
+        constexpr bool kLateInv = (MODE == 2) && !RESID;
         auto value = [&](int t, int q) {  // this lane's 4 rows (8q + 4h + 0..3) of column tile t, times act'(a_{l-1})
             const long off = off0 + q * qstride + (long)t * 32 * 8;
-            float4 v = make_float4(acc[t][4 * q] * inv, acc[t][4 * q + 1] * inv, acc[t][4 * q + 2] * inv, acc[t][4 * q + 3] * inv);
+            const float iv = kLateInv ? 1.0f : inv;
+            float4 v = make_float4(acc[t][4 * q] * iv, acc[t][4 * q + 1] * iv, acc[t][4 * q + 2] * iv, acc[t][4 * q + 3] * iv);
             if (RESID) {
                 const float4 fr = *reinterpret_cast<const float4*>(a.resid + off);
                 v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
@@ -581,7 +584,9 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
             const int i0 = (int)(tl % a.Timg) * 32 + 4 * h;
             const float4 pb = a.posebuf[b];
             const float* cbase = a.pose.coords ? a.pose.coords + (long)b * a.N * 2 : a.pose.grid;
-            float x0[16], x1[16], pd0[16], pd1[16];
+            // (x0, x1) and the two per-row partial sums are kept as float pairs: v * pair is one packed FMA (v_pk_fma_f32)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 x01[16], pd01[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -589,33 +594,39 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
                     const int i = i0 + 8 * q + r;
                     const float2 g2 = *reinterpret_cast<const float2*>(cbase + (long)(i < a.N ? i : a.N - 1) * 2);
                     const bool in = i < a.N;
-                    x0[4 * q + r] = in ? pb.x * g2.x - pb.y * g2.y + pb.z : 0.0f;
-                    x1[4 * q + r] = in ? pb.y * g2.x + pb.x * g2.y + pb.w : 0.0f;
-                    pd0[4 * q + r] = 0.0f;
-                    pd1[4 * q + r] = 0.0f;
+                    x01[4 * q + r] = (f32x2){in ? pb.x * g2.x - pb.y * g2.y + pb.z : 0.0f, in ? pb.y * g2.x + pb.x * g2.y + pb.w : 0.0f};
+                    pd01[4 * q + r] = (f32x2){0.0f, 0.0f};
                 }
+            const float late = kLateInv ? inv : 1.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int k = nb * NB + t * 32 + nl;
-                const float2 w = *reinterpret_cast<const float2*>(a.tab + ((long)b * Hp + k) * kSlots);
-                float sv = 0.0f, g0 = 0.0f, g1 = 0.0f;
+                const float2 wt = *reinterpret_cast<const float2*>(a.tab + ((long)b * Hp + k) * kSlots);
+                const f32x2 w = (f32x2){wt.x, wt.y};
+                float sv = 0.0f;
+                f32x2 g01 = (f32x2){0.0f, 0.0f};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = value(t, q);
                     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        const f32x2 vb = (f32x2){vv[r], vv[r]};
                         sv += vv[r];
-                        g0 += vv[r] * x0[4 * q + r];
-                        g1 += vv[r] * x1[4 * q + r];
-                        pd0[4 * q + r] += vv[r] * w.x;
-                        pd1[4 * q + r] += vv[r] * w.y;
+                        g01 = __builtin_elementwise_fma(vb, x01[4 * q + r], g01);
+                        pd01[4 * q + r] = __builtin_elementwise_fma(vb, w, pd01[4 * q + r]);
                     }
                 }
-                *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) = make_float4(g0, g1, sv, 0.0f);
+                *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) =
+                    make_float4(g01.x * late, g01.y * late, sv * late, 0.0f);
             }
             {
-                float s0[4], s1[4];
+                float pd0[16], pd1[16], s0[4], s1[4];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    pd0[i] = pd01[i].x;
+                    pd1[i] = pd01[i].y;
+                }
                 half_reduce16(pd0, s0);
                 half_reduce16(pd1, s1);
                 if (nl < 4) {
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const long m = tl * 32 + 8 * q + 4 * h + r;
-                        *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) = make_float2(s0[r], s1[r]);
+                        *reinterpret_cast<float2*>(a.dfpart + ((long)nb * a.Mp + m) * 2) = make_float2(s0[r] * late, s1[r] * late);
                     }
                 }
             }
@@ -728,8 +739,18 @@ __global__ void colsum_reduce_kernel(const float* __restrict__ hbpart, float* __
     const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + col;
     float s = 0.0f;
-    if (n < Hp)  // Hp is the row stride; callers with unpadded rows (svae_colsum) have columns past it in the last block
-        for (int i = pl; i < nparts; i += 8) s += hbpart[(long)i * Hp + n];
+    if (n < Hp) {  // Hp is the row stride; callers with unpadded rows (svae_colsum) have columns past it in the last block
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;  // four chains in a fixed order: several loads in flight per thread
+        int i = pl;
+        for (; i + 24 < nparts; i += 32) {
+            s += hbpart[(long)i * Hp + n];
+            s1 += hbpart[(long)(i + 8) * Hp + n];
+            s2 += hbpart[(long)(i + 16) * Hp + n];
+            s3 += hbpart[(long)(i + 24) * Hp + n];
+        }
+        for (; i < nparts; i += 8) s += hbpart[(long)i * Hp + n];
+        s = (s + s1) + (s2 + s3);
+    }
     red[pl][col] = s;
     __syncthreads();
     if (pl == 0 && n < H) {
