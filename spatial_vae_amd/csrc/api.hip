@@ -380,8 +380,8 @@ template <int NT>
 void launch_split_bwd_c(const SplitArgs& a, dim3 grid, bool first, bool resid, hipStream_t st) {
     constexpr int lds = SplitCfg<NT>::LDS_BYTES;
     if (first) {
-        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 2, true, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
-        else hipLaunchKernelGGL((dense_split_kernel<NT, 2, false, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
+        if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 2, true, 0>), grid, dim3(SplitWaves<2>::value * 64), lds, st, a);
+        else hipLaunchKernelGGL((dense_split_kernel<NT, 2, false, 0>), grid, dim3(SplitWaves<2>::value * 64), lds, st, a);
     } else {
         if (resid) hipLaunchKernelGGL((dense_split_kernel<NT, 1, true, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
         else hipLaunchKernelGGL((dense_split_kernel<NT, 1, false, 0>), grid, dim3(kSplitWaves * 64), lds, st, a);
@@ -403,8 +403,8 @@ int split_nt_fwd(const Geo& g) {  // SVAE_SPLIT_NT8=1: 8 tiles per forward pass 
     return (nt8 && g.ntile % 8 == 0) ? 8 : split_nt(g);
 }
 
-dim3 split_grid(const Geo& g, int nt) {  // see dense_split_kernel: (xcd, column block, group / 8)
-    const long groups = (g.tiles + kSplitWaves - 1) / kSplitWaves;
+dim3 split_grid(const Geo& g, int nt, int waves = kSplitWaves) {  // see dense_split_kernel: (xcd, column block, group / 8)
+    const long groups = (g.tiles + waves - 1) / waves;
     return dim3((unsigned)(((groups + 7) / 8) * 8 * (g.ntile / nt)));
 }
 
@@ -457,7 +457,7 @@ void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     } a.posebuf = pl.posebuf; a.tab = pl.tab; a.sgtile = pl.sgtile;
     a.dfpart = pl.dfpart; a.N = g.N; a.Timg = g.Timg;
     const int nt = split_nt(g);
-    const dim3 grid = split_grid(g, nt);
+    const dim3 grid = split_grid(g, nt, first ? SplitWaves<2>::value : SplitWaves<1>::value);
     if (nt == 4) launch_split_bwd_c<4>(a, grid, first, resid, st);
     else launch_split_bwd_c<2>(a, grid, first, resid, st);
     if (!first)  // scale of the plane just written, for the layer below (stream order: after the GEMM, before its consumers)

@@ -307,8 +307,19 @@ struct SplitCfg {
 #define SVAE_SPLIT_WAVES 8
 #endif
 constexpr int kSplitWaves = SVAE_SPLIT_WAVES;
+// waves per workgroup of a variant: the fused first-layer data gradient keeps ~230 registers, i.e. two waves per SIMD; as ONE
+// 8-wave workgroup per CU all of them are in the same phase and nothing overlaps its long epilogue (27 % of the kernel)
+// -- as two independent 4-wave workgroups the epilogue of one runs under the MFMA loop of the other.
+#ifndef SVAE_SPLIT_WAVES_M2
+#define SVAE_SPLIT_WAVES_M2 4
+#endif
+template <int MODE>
+struct SplitWaves {
+    static constexpr int value = MODE == 2 ? SVAE_SPLIT_WAVES_M2 : kSplitWaves;
+};
 template <int NT, int MODE, bool RESID, int CF>
-__global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void dense_split_kernel(SplitArgs a) {
+__global__ __launch_bounds__(SplitWaves<MODE>::value * 64, (SplitWaves<MODE>::value == 8 ? 1 : (MODE == 2 ? 2 : 3))) void dense_split_kernel(SplitArgs a) {
+    constexpr int WV = SplitWaves<MODE>::value;
     static_assert(CF == 0 || MODE == 0, "CF is a forward epilogue");
     extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
     using Cfg = SplitCfg<NT>;
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
     const long local = blockIdx.x >> 3;
     const int nb = (int)(local % nblk);  // column block of NT tiles
     const long group = (local / nblk) * 8 + (blockIdx.x & 7);
-    const long tile = group * kSplitWaves + wave;
+    const long tile = group * WV + wave;
     const bool live = tile < a.tiles;
     const long tl = live ? tile : a.tiles - 1;
     const int nchunk = KC / G;
@@ -351,16 +362,16 @@ __global__ __launch_bounds__(kSplitWaves * 64, (kSplitWaves == 8 ? 1 : 3)) void 
     //   step g needs A(g) of this chunk (issued in the previous one): behind it are 2(G-1-g) A loads of that chunk,
     //   this chunk's P pieces and 2g A loads -> vmcnt(2(G-1) + P), one constant for every step;
     //   the barrier needs this wave's pieces of chunk c (issued at the top of chunk c-1): behind them 2G A loads.
-    constexpr int P = BLOCKS / kSplitWaves;  // 1 KiB pieces per wave and chunk
-    static_assert(BLOCKS % kSplitWaves == 0, "the chunk must divide over the waves");
+    constexpr int P = BLOCKS / WV;  // 1 KiB pieces per wave and chunk
+    static_assert(BLOCKS % WV == 0, "the chunk must divide over the waves");
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)smem4;
-    // Addresses are prepared once: piece j of this wave is block idx = wave + kSplitWaves j of a chunk; its source offset inside
+    // Addresses are prepared once: piece j of this wave is block idx = wave + WV j of a chunk; its source offset inside
     // the chunk and its LDS address are loop-invariant, the chunk base advances by a scalar add.  (Computed per piece
     // inside the loop this was ~130 instructions per 48 MFMAs: a third of the kernel.)
     unsigned poff[P], pm0[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        const int idx = wave + kSplitWaves * j;
+        const int idx = wave + WV * j;
         const int part = idx & 1, t = (idx >> 1) % NT, g = (idx >> 1) / NT;
         poff[j] = (unsigned)((((g * ntile + nb * NT + t) * 2 + part) * 64 + lane) * 16);
         pm0[j] = lds_base + (unsigned)idx * 1024u;  // scalar: wave and the LDS base are SGPR values
