@@ -279,7 +279,7 @@ struct SplitArgs {
 };
 
 // timing-only ablation switches (never set in the product build): 1 = every tile reads the rows of tile 0 (L2-hot row
-// operand), 2 = no result stores, 4 = no weight DMA / barrier in the loop, 8 = no weight-fragment LDS reads in the loop, 128 = no data-gradient epilogue
+// operand), 2 = no result stores, 4 = no weight DMA / barrier in the loop, 8 = no weight-fragment LDS reads in the loop, 128 = no data-gradient epilogue, 256 = weight gradient without DMA in the loop, 512 = without barriers
 #ifndef SVAE_SPLIT_ABLATE
 #define SVAE_SPLIT_ABLATE 0
 #endif
@@ -803,12 +803,19 @@ struct SplitWgradArgs {
     long nsteps;         // Mp / 16
     int Hp, nblk1, S;    // nblk1 = 256-wide blocks per side, S = row-range splits
 };
-constexpr int kSplitWgradLds = 3 * 32 * 1024;
+constexpr int kSplitWgradLds = 4 * 32 * 1024;
 
 // One 256 x 256 block of dW per workgroup (blockIdx.x), one range of 16-row steps per blockIdx.y.  Per step the
-// workgroup stages 8 + 8 feature tiles x (hi, lo) = 32 KiB by LDS-DMA (two steps ahead, three buffers); wave (wi, wj)
+// workgroup stages 8 + 8 feature tiles x (hi, lo) = 32 KiB by LDS-DMA (two steps ahead, four buffers, one barrier per two
+// steps); wave (wi, wj)
 // reads its 4 + 4 tiles from LDS and issues 4 x 4 x 3 MFMAs into 256 accumulator registers.
-template <bool BIAS>  // BIAS: also sum the gradient's columns (db); false when out_bwd_split_kernel already did
+// PRIV: every wave stages its OWN 4 + 4 tiles into a private two-slot ring (16 KiB per slot) and the kernel has no barrier at
+// all -- twice the L2 -> LDS traffic, but with one wave per SIMD a workgroup barrier stalls the matrix pipe of all four
+// SIMDs (ablation: 0.31 ms with barriers, 0.22 ms without); !PRIV is the shared four-buffer scheme.
+#ifndef SVAE_SPLIT_WGRAD_PRIV
+#define SVAE_SPLIT_WGRAD_PRIV 1
+#endif
+template <bool BIAS, bool PRIV = (SVAE_SPLIT_WGRAD_PRIV != 0)>  // BIAS: also sum the gradient's columns (db)
 __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -865,54 +872,94 @@ __global__ __launch_bounds__(256, 1) void split_wgrad_kernel(SplitWgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) glds16_s(j < 4 ? gb : ab, poff[j], pm0[j] + bufoff);
     };
-    if (nst > 0) {
-        stage(gbase, abase, 0u);
-        const unsigned adv0 = nst > 1 ? step_bytes : 0u;
-        gbase += adv0;
-        abase += adv0;
-        stage(gbase, abase, 32u * 1024u);
-        for (int c = 0; c < nst; ++c) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's pieces of step c (behind them: step c+1's 8)
-            __syncthreads();
-            const unsigned adv = c + 2 < nst ? step_bytes : 0u;  // past the end: re-stage the last step (never read)
-            gbase += adv;
-            abase += adv;
-            stage(gbase, abase, (unsigned)((c + 2) % 3) * 32u * 1024u);
-            const uint4* buf = smw + (c % 3) * 2048;
-            // one wave per SIMD: nothing else hides the LDS latency, so the activation fragments of column tile j+1 are
-            // read while the 12 MFMAs of tile j run (sched_barrier pins the order the source states)
-            Frag gh[4], gl[4], ah[2], al[2];
+    // PRIV: this wave's 16 pieces of a step: block p = (which * 4 + i) * 2 + part of its slot (which 0 = gradient tile
+    // wi*4 + i, 1 = activation tile wj*4 + i)
+    unsigned qoff[16], qm0[16];
+    if (PRIV) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int part = p & 1, i = (p >> 1) & 3, which = p >> 3;
+            int ft = which ? bk * 8 + wj * 4 + i : bn * 8 + wi * 4 + i;
+            ft = ft < FT ? ft : FT - 1;
+            qoff[p] = (unsigned)(((ft * 2 + part) * 64 + lane) * 16);
+            qm0[p] = lds_base + (unsigned)(wave * 32 + p) * 1024u;  // wave's ring: 2 slots x 16 KiB
+        }
+    }
+    auto stage_priv = [&](const char* gb, const char* ab, unsigned slotoff) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) glds16_s(p < 8 ? gb : ab, qoff[p], qm0[p] + slotoff);
+    };
+    // fragment addresses inside a step's LDS image: shared (32 blocks: gradient tiles 0..7, activation tiles 8..15) or private
+    const int gtile0 = PRIV ? 0 : wi * 4, atile0 = PRIV ? 4 : 8 + wj * 4;
+    auto compute_step = [&](const uint4* buf) {
+        // one wave per SIMD: nothing else hides the LDS latency, so the activation fragments of column tile j+1 are
+        // read while the 12 MFMAs of tile j run (sched_barrier pins the order the source states)
+        // reads in the order the first MFMAs need them (LDS returns in order): the first product can issue after two reads
+        Frag gh[4], gl[4], ah[2], al[2];
+        ah[0].u = buf[(atile0 * 2) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gh[i].u = buf[((gtile0 + i) * 2) * 64 + lane];
+        al[0].u = buf[(atile0 * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl[i].u = buf[((gtile0 + i) * 2 + 1) * 64 + lane];
+        if (BIAS && wj == 0) {  // bias gradient: column sums of the gradient tiles
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gh[i].u = buf[((wi * 4 + i) * 2) * 64 + lane];
-                gl[i].u = buf[((wi * 4 + i) * 2 + 1) * 64 + lane];
+                float t = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t += (float)gh[i].h[e] + (float)gl[i].h[e];
+                bs[i] += t;
             }
-            ah[0].u = buf[(16 + (wj * 4) * 2) * 64 + lane];
-            al[0].u = buf[(16 + (wj * 4) * 2 + 1) * 64 + lane];
-            if (BIAS && wj == 0) {  // bias gradient: column sums of the gradient tiles
+        }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float t = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t += (float)gh[i].h[e] + (float)gl[i].h[e];
-                    bs[i] += t;
-                }
+        for (int j = 0; j < 4; ++j) {
+            if (j + 1 < 4) {
+                ah[(j + 1) & 1].u = buf[((atile0 + j + 1) * 2) * 64 + lane];
+                al[(j + 1) & 1].u = buf[((atile0 + j + 1) * 2 + 1) * 64 + lane];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // the three products of one accumulator are three MFMAs apart (four independent accumulators in between)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j + 1 < 4) {
-                    ah[(j + 1) & 1].u = buf[(16 + (wj * 4 + j + 1) * 2) * 64 + lane];
-                    al[(j + 1) & 1].u = buf[(16 + (wj * 4 + j + 1) * 2 + 1) * 64 + lane];
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, ah[j & 1].h, acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, ah[j & 1].h, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, al[j & 1].h, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[i].h, ah[j & 1].h, acc[i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[i].h, al[j & 1].h, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl[i].h, ah[j & 1].h, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (PRIV && nst > 0) {
+        const uint4* ring = smw + wave * 2048;  // 32 KiB per wave
+        stage_priv(gbase, abase, 0u);
+        for (int c = 0; c < nst; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step c; nobody else reads them: no barrier
+            const long sn = c + 1 < nst ? c + 1 : c;          // past the end: re-stage the last step (never read)
+            if (!(SVAE_SPLIT_ABLATE & 256))
+                stage_priv(gbase + sn * (long)step_bytes, abase + sn * (long)step_bytes, (unsigned)((c + 1) & 1) * 16u * 1024u);
+            compute_step(ring + (c & 1) * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage must have landed before the wave ends
+    } else if (nst > 0) {
+        // four 32 KiB buffers, one barrier per TWO steps: at the barrier before steps (c, c+1) every wave has waited for its
+        // pieces of both, nobody reads buffers (c+2) % 4 and (c+3) % 4 any more (steps c-2, c-1), and steps c+2, c+3 go out
+        // into them -- two steps (~3000 MFMA cycles) ahead of their use
+        int snext = 0;  // next step to stage; past the end the last step is re-staged (never read)
+        auto stage_next = [&]() {
+            const long sidx = snext < nst ? snext : nst - 1;
+            stage(gbase + sidx * (long)step_bytes, abase + sidx * (long)step_bytes, (unsigned)(snext & 3) * 32u * 1024u);
+            ++snext;
+        };
+        stage_next();
+        stage_next();
+        for (int c = 0; c < nst; c += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(SVAE_SPLIT_ABLATE & 512) || c == 0) __syncthreads();
+            if (!(SVAE_SPLIT_ABLATE & 256)) {
+                stage_next();
+                stage_next();
             }
+            compute_step(smw + (c & 3) * 2048);
+            if (c + 1 < nst) compute_step(smw + ((c + 1) & 3) * 2048);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
