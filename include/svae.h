@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SVAE_ABI_VERSION 1
+#define SVAE_ABI_VERSION 2
 #define SVAE_MAX_HIDDEN 7 /* hidden H x H layers = num_layers - 1 */
 #define SVAE_MAX_OUT 4    /* n_out (channels) */
 
@@ -245,8 +245,12 @@ int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, cons
  *            bfactor, ampcont [%], dfdiff (unused by the reference), dfang [deg].
  *   filters  (count, n, m) fp32 out -- the `ctf` operand of svae_gaussian_loglik.
  * Arithmetic is in doubles like numpy's; the result agrees with the reference to fp32 rounding.
+ * Filters of up to ~80 x 80 are transformed entirely in the LDS of one CU and need no scratch (the workspace size is 0 and
+ * ws may be NULL); larger ones (the reference's numpy code has no size limit) keep their intermediate planes in `ws`.
  */
-int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, svae_stream_t stream);
+size_t svae_ctf_filter_workspace_bytes(int32_t count, int32_t n, int32_t m);
+int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, void* ws,
+                    size_t ws_bytes, svae_stream_t stream);
 
 /*
  * How the hidden-layer GEMMs are computed.  SVAE_GEMM_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products.

@@ -13,10 +13,18 @@ MAX_HIDDEN = 7
 ACT = {"tanh": 0, "leakyrelu": 1, "relu": 2, "sigmoid": 3}
 FLAG_RESID, FLAG_BILINEAR, FLAG_SOFTPLUS = 1, 2, 4
 
-EXPORTS = ("svae_abi_version", "svae_last_error", "svae_saved_bytes", "svae_workspace_bytes",
-           "svae_decoder_forward", "svae_decoder_backward", "svae_bce_loglik",
-           "svae_gaussian_workspace_bytes", "svae_gaussian_loglik", "svae_profile_enable", "svae_profile_read",
-           "svae_profile_kind_name", "svae_latent_forward", "svae_latent_backward", "svae_adam_step")
+ABI_VERSION = 2
+
+
+def _declared_symbols():
+    """Every function include/svae.h declares -- build() and the tests check that the library exports all of them."""
+    import re
+    header = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "svae.h")
+    with open(header) as f:
+        return tuple(sorted(set(re.findall(r"\b(svae_[a-z0-9_]+)\s*\(", f.read()))))
+
+
+EXPORTS = _declared_symbols()
 PROF_KINDS = 16
 
 
@@ -94,7 +102,9 @@ def lib():
     L.svae_rotate_bicubic.restype = ctypes.c_int
     L.svae_rotate_bicubic.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svae_ctf_filter.restype = ctypes.c_int
-    L.svae_ctf_filter.argtypes = [vp, vp, i32, i32, i32, ctypes.c_double, vp]
+    L.svae_ctf_filter_workspace_bytes.restype = sz
+    L.svae_ctf_filter_workspace_bytes.argtypes = [i32, i32, i32]
+    L.svae_ctf_filter.argtypes = [vp, vp, i32, i32, i32, ctypes.c_double, vp, sz, vp]
     L.svae_gemm_mode_set.restype = ctypes.c_int
     L.svae_gemm_mode_set.argtypes = [ctypes.c_int]
     L.svae_gemm_mode_get.restype = ctypes.c_int
@@ -104,8 +114,9 @@ def lib():
     L.svae_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     L.svae_profile_kind_name.restype = ctypes.c_char_p
     L.svae_profile_kind_name.argtypes = [ctypes.c_int]
-    if L.svae_abi_version() != 1:
-        raise RuntimeError("spatial_vae_amd: ABI version mismatch")
+    if L.svae_abi_version() != ABI_VERSION:
+        raise RuntimeError("spatial_vae_amd: %s has ABI version %d, this binding needs %d -- rebuild it"
+                           % (path, L.svae_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

@@ -13,6 +13,7 @@ archive, dataset download and MRC input (raises).  `--augment_rotation` runs on 
 (train on N synthetic images when no data files exist), data-parallel execution under torchrun, and
 `--progress_every` (the reference pays three .item() syncs per step for its progress line).
 """
+import copy
 import math
 import os
 import sys
@@ -27,19 +28,21 @@ from . import elbo as E
 
 
 class RunningMean(object):
-    """acc += b * (v - acc) / count  (train_mnist.py:156-164), kept on the device in float64."""
+    """acc += b * (v - acc) / count  (train_mnist.py:156-164), kept on the device in float64.  `vec` is the
+    (elbo, log_p, kl) vector of one minibatch; the reference logs -log_p ("gen_loss"), and since negation commutes
+    with this arithmetic bit for bit, the sign is applied when the values are read."""
 
     def __init__(self, device, n=3):
         self.acc = torch.zeros(n, dtype=torch.float64, device=device)
         self.count = 0
 
-    def update(self, batch_size, values):
+    def update(self, batch_size, vec):
         self.count += batch_size
-        v = torch.stack([x.detach().double() for x in values])
-        self.acc += batch_size * (v - self.acc) / self.count
+        self.acc += batch_size * (vec.detach().double() - self.acc) / self.count
 
     def values(self):
-        return [float(x) for x in self.acc.cpu()]
+        e, lp, k = (float(x) for x in self.acc.cpu())
+        return [e, -lp, k]
 
 
 def coord_grid(n_rows, n_cols):
@@ -123,26 +126,48 @@ def export_batch_as_image(data, output, image_dims):
     Image.fromarray(image_grid(images, int(B ** 0.5))).save(output)
 
 
-def save_models(path_prefix, epoch_str, p_net, q_net, device):
-    """torch.save(<whole module>) under the reference's names (src/misc_tools.py:88-104)."""
+def save_models(path_prefix, epoch_str, p_net, q_net, device=None):
+    """torch.save(<whole module>) under the reference's names (src/misc_tools.py:88-104).  The reference moves the live
+    module (net.eval().cpu(), save, net.cuda()); here a detached CPU COPY is saved instead: the live parameters are
+    views into dp.TrainStep's flat buffers, and a Module._apply round trip would re-allocate them -- the optimiser
+    would keep stepping the orphaned flat buffer while the forward pass read stale module tensors."""
     for tag, net in (("generator", p_net), ("inference", q_net)):
         sinks = net.__dict__.pop("_grad_sinks", None)       # views into a training buffer: not part of the model
-        net.eval().cpu()
-        torch.save(net, "{}_{}_epoch{}.sav".format(path_prefix, tag, epoch_str))
-        net.to(device)
-        if sinks is not None:
-            net._grad_sinks = sinks
+        try:
+            snapshot = copy.deepcopy(net).eval().cpu()
+        finally:
+            if sinks is not None:
+                net._grad_sinks = sinks
+        torch.save(snapshot, "{}_{}_epoch{}.sav".format(path_prefix, tag, epoch_str))
+
+
+def _metric_vector(out):
+    """(elbo, log_p, kl) of an eval_minibatch result as one 3-vector (ops.elbo_head returns views of one)."""
+    base = getattr(out[0], "_base", None)
+    if base is not None and base.numel() == 3:
+        return base.detach()
+    return torch.stack([out[0].detach(), out[1].detach(), out[2].detach()])
 
 
 def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world, progress_every, extra):
-    """One pass over `batches` (a list of index tensors into the resident data).  Training uses
-    dp.TrainStep (forward, backward, all-reduce, Adam); evaluation only the forward (it is stochastic in
-    the reference too: eval_model draws noise, train_mnist.py:174-226)."""
+    """One pass over `batches` (a list of index tensors into the resident data; every rank holds the same list).
+    Training uses dp.TrainStep (forward, backward, all-reduce, Adam); evaluation only the forward (it is stochastic in
+    the reference too: eval_model draws noise, train_mnist.py:174-226).
+
+    Data parallel: rank g works on rows [lo, hi) of each GLOBAL minibatch.  The N(0,1) draw is made for the whole
+    global minibatch from a generator every rank seeded identically (extra["noise_gen"]) and sliced like the data, and
+    so are the augmentation angles, so a G-rank step computes what the 1-rank step computes (up to fp32 summation
+    order).  Training metrics come back inside the gradient all-reduce (step.metrics); evaluation metrics are
+    collected per batch and all-reduced ONCE per epoch.  A rank with an empty slice (ragged last batch smaller than the
+    world) contributes zeros."""
     p_net, q_net = step.p_net, step.q_net
     p_net.train(train)
     q_net.train(train)
     data = extra["data"]
     mean = RunningMean(x.device)
+    inf_dim = extra["inf_dim"]
+    noise_list = extra.get("noise")
+    pending = []
     for it, idx in enumerate(batches):
         gb = idx.numel()
         lo, hi = dp.shard_bounds(gb, rank, world)
@@ -153,25 +178,41 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
             ctf = data["ctf"][sel] if data.get("ctf") is not None else None
             args = (y, extra.get("mask"), ctf)
         kw = dict(extra.get("kw", {}))
+        if noise_list is not None:
+            r = noise_list[it]
+        else:
+            r = torch.empty(gb, inf_dim, device=x.device, dtype=torch.float32).normal_(generator=extra["noise_gen"])
+        kw["noise"] = r[lo:hi]
+        out = None
         if train:
             kw.update(extra.get("train_kw", {}))        # augmentation applies to training steps only (train_galaxy.py:204)
+            if world > 1 and kw.get("augment_rotation") and step.eval_kwargs.get("rotate"):
+                kw["offset"] = E.draw_offsets(step.eval_kwargs["rotate"], gb)[lo:hi]   # np.random is seeded alike on all ranks
             out = step(x, *args, weight=(hi - lo) / gb, **kw)
+            mean.update(gb, step.metrics)
         else:
-            with torch.no_grad():
-                call = dict(step.eval_kwargs)
-                call.update(kw)
-                out = step.eval_minibatch(x, *args, p_net, q_net, **call)
-        elbo, log_p, kl = out[0], out[1], out[2]
-        if it == 0 and extra.get("dump") and rank == 0:            # first batch of a save-interval epoch (train_mnist.py:214-224)
+            vals = torch.zeros(3, device=x.device)
+            if hi > lo:
+                with torch.no_grad():
+                    call = dict(step.eval_kwargs)
+                    call.update(kw)
+                    out = step.eval_minibatch(x, *args, p_net, q_net, **call)
+                vals = _metric_vector(out)
+            if world > 1:
+                pending.append((gb, vals * ((hi - lo) / gb)))
+            else:
+                mean.update(gb, vals)
+        if it == 0 and extra.get("dump") and rank == 0 and out is not None:   # first batch of a save-interval epoch (train_mnist.py:214-224)
             extra["dump"](y, out[3] if len(out) > 3 else None)
-        vals = torch.stack([elbo.detach(), -log_p.detach(), kl.detach()]) * ((hi - lo) / gb)
-        if world > 1:
-            torch.distributed.all_reduce(vals)
-        mean.update(gb, list(vals))
         if train and rank == 0 and progress_every > 0 and (it + 1) % progress_every == 0:
             e, g, k = mean.values()
             print("# [{}/{}] training {:.1%}, ELBO={:.5f}, Error={:.5f}, KL={:.5f}".format(
                 epoch + 1, num_epochs, mean.count / N, e, g, k), end="\r", file=sys.stderr)
+    if pending:
+        allv = torch.stack([v for _, v in pending])
+        torch.distributed.all_reduce(allv)
+        for (gb, _), v in zip(pending, allv):
+            mean.update(gb, v)
     if train and rank == 0 and progress_every > 0:
         print(" " * 80, end="\r", file=sys.stderr)
     return mean.values()
@@ -212,8 +253,16 @@ def train_main(script, args, build):
     mask = cfg.get("mask")
     mask = mask.to(device) if mask is not None else None
     N = tr["y"].size(0)
+    # one seed for the whole job (rank 0's): the shuffle, the global noise draw and -- under DP -- the augmentation
+    # angles are then the same on every rank, which each slices [lo:hi)
+    seed = dp.shared_seed(device)
     gen = torch.Generator()
-    gen.manual_seed(torch.initial_seed())
+    gen.manual_seed(seed)
+    noise_gen = torch.Generator(device=device)
+    noise_gen.manual_seed(seed)
+    if world > 1:
+        np.random.seed(seed % (2 ** 32))
+    inf_dim = q_net.latent_dim
     out = sys.stdout
     header = cfg["table"]
     if rank == 0:
@@ -231,7 +280,7 @@ def train_main(script, args, build):
         batches = [perm[i:i + bs].to(device) for i in range(0, N, bs)]
         train_kw = {"augment_rotation": True} if cfg.get("augment") and script != "mnist" else {}
         e, g, k = run_epoch(script, step, x, batches, True, N, epoch, num_epochs, rank, world, args.progress_every,
-                            dict(data=tr, mask=mask, kw=kw, train_kw=train_kw))
+                            dict(data=tr, mask=mask, kw=kw, train_kw=train_kw, inf_dim=inf_dim, noise_gen=noise_gen))
         ntest = te["y"].size(0)
         order = torch.arange(ntest)
         tb = [order[i:i + bs].to(device) for i in range(0, ntest, bs)]
@@ -239,7 +288,7 @@ def train_main(script, args, build):
         if out_dir and script != "particles" and (epoch + 1) % args.save_interval == 0:
             dump = _image_dumper(script, step, x, cfg, out_dir, str(epoch + 1).zfill(digits), label, kw, args.z_dim)
         ev = run_epoch(script, step, x, tb, False, ntest, epoch, num_epochs, rank, world, 0,
-                       dict(data=te, mask=mask, kw=kw, dump=dump))
+                       dict(data=te, mask=mask, kw=kw, dump=dump, inf_dim=inf_dim, noise_gen=noise_gen))
         if rank == 0:
             if script == "particles":
                 print("\t".join([str(epoch + 1), "train", str(e), str(g), str(k)]), file=out)

@@ -1015,17 +1015,42 @@ int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, cons
     return launch_status("svae_rotate_bicubic");
 }
 
-int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, svae_stream_t stream) {
+namespace {
+const size_t CTF_LDS_MAX = 160 * 1024;
+const int CTF_SCRATCH_GROUPS = 512;  // workgroups of the scratch form (two per CU); each strides over the particles
+size_t ctf_lds_bytes(int n, int m) { return ((size_t)n * m * 3 + 2 * ((size_t)n + m)) * sizeof(double); }
+}  // namespace
+
+size_t svae_ctf_filter_workspace_bytes(int32_t count, int32_t n, int32_t m) {
+    if (count < 1 || n < 1 || m < 1) return 0;
+    if (ctf_lds_bytes(n, m) <= CTF_LDS_MAX) return 0;  // the whole transform fits the LDS of one CU
+    const size_t groups = (size_t)(count < CTF_SCRATCH_GROUPS ? count : CTF_SCRATCH_GROUPS);
+    return groups * (size_t)n * m * 3 * sizeof(double);
+}
+
+int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, void* ws,
+                    size_t ws_bytes, svae_stream_t stream) {
     if (!params || !filters || count < 1 || n < 1 || m < 1) return fail(SVAE_E_INVALID, "svae_ctf_filter: bad arguments");
-    const size_t lds = ((size_t)n * m * 3 + 2 * ((size_t)n + m)) * sizeof(double);
-    if (lds > 160 * 1024) return fail(SVAE_E_INVALID, "svae_ctf_filter: %d x %d filters do not fit the LDS (max ~80 x 80)", n, m);
+    if (n > 8192 || m > 8192) return fail(SVAE_E_INVALID, "svae_ctf_filter: %d x %d filters are not supported (max 8192)", n, m);
     if (!(scale > 0.0)) return fail(SVAE_E_INVALID, "svae_ctf_filter: scale must be positive");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return fail(SVAE_E_LAUNCH, "svae_ctf_filter: cannot reserve %zu bytes of LDS", lds);
+    const size_t lds = ctf_lds_bytes(n, m);
     Scope prof(K_AUGMENT, st);
-    hipLaunchKernelGGL(ctf_filter_kernel, dim3(count), dim3(256), lds, st, params, filters, n, m, scale);
+    if (lds <= CTF_LDS_MAX) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_filter_kernel<false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(SVAE_E_LAUNCH, "svae_ctf_filter: cannot reserve %zu bytes of LDS", lds);
+        hipLaunchKernelGGL(ctf_filter_kernel<false>, dim3(count), dim3(256), lds, st, params, filters, count, n, m, scale,
+                           static_cast<double*>(nullptr));
+    } else {
+        const size_t need = svae_ctf_filter_workspace_bytes(count, n, m);
+        if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 255))
+            return fail(SVAE_E_WORKSPACE, "svae_ctf_filter: %d x %d filters need %zu bytes of 256-byte aligned scratch (got %zu)",
+                        n, m, need, ws_bytes);
+        const int groups = count < CTF_SCRATCH_GROUPS ? count : CTF_SCRATCH_GROUPS;
+        hipLaunchKernelGGL(ctf_filter_kernel<true>, dim3(groups), dim3(256), 2 * ((size_t)n + m) * sizeof(double), st, params,
+                           filters, count, n, m, scale, static_cast<double*>(ws));
+    }
     return launch_status("svae_ctf_filter");
 }
 

@@ -906,16 +906,22 @@ __global__ void rotate_bicubic_kernel(const float* __restrict__ y, float* __rest
 // with a separable inverse DFT (rows, then columns; doubles throughout, the sizes are ~39 x 39), fftshift, negate, store
 // as float.  params row = [defocus um, cs mm, voltage kV, apix A, bfactor, ampcont %, dfdiff, dfang deg]
 // (ctf.py:29); as in the reference dfdiff is unused: both defoci are defocus*10000 (ctf.py:47-48).
-// LDS: c (n*m doubles) | T (n*m double2) | twiddles of length m and n (double2 each).
-__global__ void __launch_bounds__(256) ctf_filter_kernel(const double* __restrict__ params, float* __restrict__ out, int n, int m,
-                                                          double scale) {
+// LDS: c (n*m doubles) | T (n*m double2) | twiddles of length m and n (double2 each).  SCRATCH = true (filters above
+// ~80 x 80, whose 24 n m bytes exceed the 160 KiB of LDS): c and T live in a per-workgroup slice of a caller-provided
+// global scratch area instead (only the twiddles stay in LDS) and the grid strides over the particles; same arithmetic
+// in the same order, so both forms give identical bits.
+template <bool SCRATCH>
+__global__ void __launch_bounds__(256) ctf_filter_kernel(const double* __restrict__ params, float* __restrict__ out, int count,
+                                                          int n, int m, double scale, double* __restrict__ scratch) {
 #pragma clang fp contract(off)
     extern __shared__ double lds_ctf[];
-    double* c = lds_ctf;
+    double* c = SCRATCH ? scratch + (long)blockIdx.x * 3 * n * m : lds_ctf;
     double2* T = reinterpret_cast<double2*>(c + (long)n * m);
-    double2* wm = T + (long)n * m;
+    double2* wm = SCRATCH ? reinterpret_cast<double2*>(lds_ctf) : T + (long)n * m;
     double2* wn = wm + m;
-    const double* p = params + (long)blockIdx.x * 8;
+    for (int particle = blockIdx.x; particle < count; particle += gridDim.x) {
+    __syncthreads();   // the previous particle's last pass has finished reading T and the twiddles
+    const double* p = params + (long)particle * 8;
     const double apix = p[3] * scale;
     const double dfu = p[0] * 10000.0, dfv = p[0] * 10000.0;
     const double dfang = 2.0 * M_PI * p[7] / 360.0;
@@ -958,7 +964,7 @@ __global__ void __launch_bounds__(256) ctf_filter_kernel(const double* __restric
     }
     __syncthreads();
     const double inv = 1.0 / ((double)n * m);
-    float* o = out + (long)blockIdx.x * n * m;
+    float* o = out + (long)particle * n * m;
     for (int e = threadIdx.x; e < n * m; e += 256) {  // out[i][j] = -Re X[(i + (n+1)/2) % n][(j + (m+1)/2) % m]
         const int i = e / m, j = e - i * m;
         const int u = (i + (n + 1) / 2) % n, v = (j + (m + 1) / 2) % m;
@@ -971,6 +977,7 @@ __global__ void __launch_bounds__(256) ctf_filter_kernel(const double* __restric
             if (k >= n) k -= n;
         }
         o[e] = (float)(-(re * inv));
+    }
     }
 }
 

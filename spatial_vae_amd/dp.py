@@ -5,13 +5,24 @@ The reference is single-device; this is the build's mult
 so rank g of G takes a contiguous slice of each global minibatch, computes the gradient of its
 local mean weighted by local_count / global_count, and ONE all-reduce (sum) of the flat fp32
 gradient over xGMI yields the gradient of the global mean.  All ranks hold full replicas of
-p_net, q_net and the Adam state and apply the identical update, so no broadcast is needed.
+p_net, q_net and the Adam state; TrainStep broadcasts rank 0's parameters once at construction
+(every process initialises its modules from its own RNG) and from then on all ranks apply the
+identical Adam update to identical gradients, so no further broadcast is needed.
 
 Every parameter's .grad is a view into one flat buffer, so the collective runs on the buffer the
-backward pass wrote -- no pack/unpack copies.  Backend: "nccl" (= RCCL on ROCm) when the
-parameters live on a GPU, "gloo" on CPU (tests).
+backward pass wrote -- no pack/unpack copies.  The buffer is laid out [p_net | q_net | 3 metrics]:
+the decoder's gradients are complete as soon as svae_decoder_backward has been enqueued, so their
+bucket is all-reduced on a side stream while autograd is still running the encoder's backward;
+the second bucket (q_net plus the three logged scalars elbo, log_p, kl, pre-weighted like the
+gradients) follows when backward() returns.  Two collectives per step, none for logging.
+Backend: "nccl" (= RCCL on ROCm) when the parameters live on a GPU, "gloo" on CPU (tests) and
+for the shared-GPU rehearsal (SVAE_SHARE_GPU=1: every rank on cuda:0).
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -39,6 +50,45 @@ def init_process_group(device_is_gpu):
     return rank, world, local
 
 
+def launch_ranks(nproc, argv, env=None, poll=0.2):
+    """Start `nproc` fresh Python processes running `argv` (script + arguments), one per GPU of this node, with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them, and wait.  Returns 0
+    when every rank exited 0, otherwise the first non-zero exit code (the remaining ranks are terminated: a dead peer
+    would leave them blocked in a collective).  The children inherit stdout/stderr, so rank 0's output is the job's.
+    The caller must not have touched the GPU: the children are new processes (fork + exec of the interpreter), never a
+    re-exec of this one."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(nproc):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+        e.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(poll)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:
+                    other.terminate()
+    for pr in procs:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    return rc
+
+
 def shard_bounds(n, rank, world):
     """Contiguous, near-equal slices; the first n % world ranks get one extra row."""
     base, extra = divmod(n, world)
@@ -57,11 +107,15 @@ class FlatGrads(object):
       .grad IS its view and autograd accumulates into it in place.
     """
 
-    def __init__(self, params, sink_params=None, flatten_params=False):
+    def __init__(self, params, sink_params=None, flatten_params=False, tail=0):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        self.n = n
+        # `tail` extra floats after the gradients ride along in the same collective (TrainStep: the logged scalars)
+        self.buffer = torch.zeros(n + tail, dtype=torch.float32, device=ref.device)
+        self.flat = self.buffer[:n]
+        self.tail = self.buffer[n:] if tail else None
         self.flat_param = None
         sink_ids = {id(p): name for name, p in (sink_params or {}).items()}
         self.sinks = {}
@@ -89,11 +143,26 @@ class FlatGrads(object):
             p.grad = None
 
     def all_reduce(self, weight=1.0):
-        """flat <- sum over ranks of weight * flat (weight = local_count / global_count)."""
+        """buffer <- sum over ranks of weight * buffer (weight = local_count / global_count)."""
         if dist.is_initialized() and dist.get_world_size() > 1:
             if weight != 1.0:
-                self.flat.mul_(weight)
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.buffer.mul_(weight)
+            dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shared_seed(device):
+    """Rank 0's torch.initial_seed(), the same integer on every rank: seeds the shuffle permutation, the global noise
+    draw and (under DP) the augmentation angles, so that every rank slices the SAME global minibatch."""
+    seed = torch.initial_seed() % (2 ** 62)
+    if world_size() > 1:
+        t = torch.tensor([seed], dtype=torch.int64, device=device)
+        dist.broadcast(t, src=0)
+        seed = int(t.item())
+    return seed
 
 
 class TrainStep(object):
@@ -104,13 +173,20 @@ class TrainStep(object):
     buffer and the metrics left on the device (the caller decides when to pay for .item()).
     torch.optim.Adam is unchanged; it simply sees ONE parameter (the flat buffer every module
     parameter is a view of), which is the same element-wise update in one kernel.
+
+    Data parallel (see the module docstring): call with this rank's slice of the global minibatch and
+    weight = local_rows / global_rows.  The weight enters as the seed of backward() (-weight instead of -1: no
+    scaling pass over the gradient buffer).  A rank whose slice is EMPTY (ragged last batch smaller than the world)
+    skips forward and backward but still joins both collectives with zeros.  After the call `metrics` holds
+    (elbo, log_p, kl) of the GLOBAL minibatch on every rank, valid until the next call.
     """
 
-    def __init__(self, p_net, q_net, eval_minibatch, lr=1e-4, fused_adam=None, **eval_kwargs):
+    def __init__(self, p_net, q_net, eval_minibatch, lr=1e-4, fused_adam=None, bucketed=None, **eval_kwargs):
         self.p_net, self.q_net = p_net, q_net
         self.eval_minibatch = eval_minibatch
         self.eval_kwargs = eval_kwargs
-        params = list(p_net.parameters()) + list(q_net.parameters())
+        p_params = [p for p in p_net.parameters() if p.requires_grad]
+        params = p_params + list(q_net.parameters())
         on_gpu = params[0].is_cuda
         sink_params = p_net.decoder_parameters() if (on_gpu and hasattr(p_net, "decoder_parameters")) else None
         q_sinks = {}
@@ -122,12 +198,17 @@ class TrainStep(object):
                     q_sinks["layers.%d.weight" % idx] = m.weight
                     q_sinks["layers.%d.bias" % idx] = m.bias
             sink_params = dict(sink_params, **q_sinks)
-        self.grads = FlatGrads(params, sink_params=sink_params, flatten_params=True)
+        self.grads = FlatGrads(params, sink_params=sink_params, flatten_params=True, tail=3)
+        self.n_p = sum(p.numel() for p in p_params)      # [0, n_p) = the decoder's bucket
+        # static (never data dependent), so that every rank issues the same collectives in the same order
+        self._bucketed = bool(sink_params) if bucketed is None else bool(bucketed)
         if sink_params:
             p_net._grad_sinks = {k: v for k, v in self.grads.sinks.items() if k not in q_sinks}
+            p_net._grad_sinks["__ready__"] = self._decoder_grads_ready
             if q_sinks:
                 q_net._grad_sinks = {k: v for k, v in self.grads.sinks.items() if k in q_sinks}
-        self._minus_one = torch.tensor(-1.0, device=params[0].device)
+        self._seeds = {}
+        self.device = params[0].device
         self.master = torch.nn.Parameter(self.grads.flat_param)
         self.master.grad = self.grads.flat
         if on_gpu and fused_adam is None:
@@ -137,14 +218,80 @@ class TrainStep(object):
             kw = {"fused": True, "capturable": True} if (fused_adam and on_gpu) else {}
             self.optim = torch.optim.Adam([self.master], lr=lr, **kw)
         self._graph = None
+        self._work_p = None
+        self._side = torch.cuda.Stream(self.device) if on_gpu else None
+        self.metrics = self.grads.tail
+        self.comm_events = None          # bench.py: (start, end) HIP events around the step's collectives
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """Make every replica rank 0's: each process initialised its modules from its own RNG."""
+        if world_size() > 1:
+            dist.broadcast(self.grads.flat_param, src=0)
+
+    def aliased(self):
+        """True while every module parameter still lives inside the flat parameter buffer (a Module._apply round trip --
+        net.cpu(), net.to() -- silently breaks that: the optimiser would then update orphaned memory)."""
+        base = self.grads.flat_param
+        lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * 4
+        return all(lo <= p.data_ptr() < hi for p in self.grads.params)
+
+    # ---- collectives ------------------------------------------------------------------------------
+    def _decoder_grads_ready(self):
+        """Called by ops._Decoder.backward once svae_decoder_backward is enqueued: every p_net gradient is final, so its
+        bucket goes out now, on a side stream, under the encoder's backward."""
+        if world_size() > 1 and self._bucketed and self._work_p is None:
+            self._work_p = self._launch(self.grads.buffer[:self.n_p], side=True)
+
+    def _launch(self, tensor, side):
+        if self._side is not None and side:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _reduce(self):
+        if world_size() == 1:
+            return
+        ev = self.comm_events
+        if self._bucketed:
+            if self._work_p is None:                      # empty shard (no backward ran): join the first bucket too
+                self._work_p = self._launch(self.grads.buffer[:self.n_p], side=True)
+            if ev:
+                ev[0].record()
+            work = [self._work_p, self._launch(self.grads.buffer[self.n_p:], side=False)]
+        else:
+            if ev:
+                ev[0].record()
+            work = [self._launch(self.grads.buffer, side=False)]
+        for w in work:
+            w.wait()                                      # the compute stream waits; the host does not
+        if ev:
+            ev[1].record()
+        self._work_p = None
+
+    def _seed(self, weight):
+        t = self._seeds.get(weight)
+        if t is None:
+            t = self._seeds[weight] = torch.tensor(-float(weight), dtype=torch.float32, device=self.device)
+        return t
 
     def _step(self, x, batch, weight, kw):
-        args = dict(self.eval_kwargs)
-        args.update(kw)
-        out = self.eval_minibatch(x, *batch, self.p_net, self.q_net, **args)
-        elbo = out[0]
-        elbo.backward(self._minus_one)                  # loss = -elbo (train_mnist.py:147-148) without a negation kernel
-        self.grads.all_reduce(weight)
+        out = None
+        rows = batch[0].size(0) if torch.is_tensor(batch[0]) else 1
+        if rows > 0:
+            args = dict(self.eval_kwargs)
+            args.update(kw)
+            out = self.eval_minibatch(x, *batch, self.p_net, self.q_net, **args)
+            elbo = out[0]
+            # loss = -elbo (train_mnist.py:147-148) without a negation kernel; under DP the seed is -local/global
+            elbo.backward(self._seed(weight))
+            base = getattr(elbo, "_base", None)           # ops.elbo_head returns views of one (elbo, log_p, kl) vector
+            vec = base if (base is not None and base.numel() == 3) else torch.stack([out[0], out[1], out[2]])
+            torch.mul(vec.detach(), float(weight), out=self.grads.tail)
+        else:
+            self.grads.tail.zero_()
+        self._reduce()
         self.optim.step()
         self.grads.zero()
         return out
@@ -161,7 +308,7 @@ class TrainStep(object):
         the C-ABI launches go to the capture stream like any torch op).  Afterwards __call__ copies the batch
         into the static input buffers and replays: ~60 kernel launches become one.  Noise is drawn inside the
         graph from torch's graph-safe Philox generator, as the reference draws it on the device."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if world_size() > 1:
             raise RuntimeError("graph capture is wired for the single-GPU step only")
         self._static_x = x
         self._static_batch = [b.clone() if torch.is_tensor(b) else b for b in batch]

@@ -42,15 +42,22 @@ def _encode(q_net, y2d):
     return torch.cat([z_mu, z_logstd], 1)
 
 
+def draw_offsets(rotate, B):
+    """The augmentation angles of train_galaxy.py:43-46 / train_particles.py:33-36 from np.random, in the reference's
+    draw order."""
+    offset = np.random.uniform(0, 2 * np.pi, size=B)
+    if rotate < 1:
+        offset = offset * np.random.binomial(1, p=rotate, size=B)
+    return offset
+
+
 def _augment(script, y, rotate, offset):
     """The reference's augmentation block: offset ~ U(0, 2 pi) per image from np.random (times a Bernoulli(rotate) when
     rotate is a probability < 1), image i rotated by offset[i] -- through uint8 for galaxy images
     (train_galaxy.py:44-54), as float32 for particles (train_particles.py:35-43)."""
     B = y.size(0)
     if offset is None:
-        offset = np.random.uniform(0, 2 * np.pi, size=B)
-        if rotate < 1:
-            offset = offset * np.random.binomial(1, p=rotate, size=B)
+        offset = draw_offsets(rotate, B)
     offset = np.asarray(offset, np.float64)
     side = int(np.sqrt(y.size(1)))
     return ops.rotate_augment(y, offset, side, side, quantize_u8=(script == "galaxy")), offset

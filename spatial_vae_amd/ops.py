@@ -161,6 +161,9 @@ class _Decoder(torch.autograd.Function):
                                                ctypes.byref(grads), _p(g_z), ctypes.byref(pg), ws.data_ptr(), ws.numel(),
                                                _stream(device)))
         ctx.saved_buf = None
+        ready = sinks.get("__ready__")   # dp.TrainStep: every decoder gradient is now enqueued -> start its all-reduce
+        if ready is not None:
+            ready()
 
         def ret(t, key):
             """A gradient the kernels wrote straight into the caller's sink is not handed to autograd again
@@ -175,7 +178,8 @@ class _Decoder(torch.autograd.Function):
 def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, sinks=None):
     """Returns (y, logits), each (B, N, n_out).  Exactly one of coords / grid is given.
     sinks: optional {name: tensor} of preallocated parameter-gradient buffers (names coord_w, coord_b,
-    latent_w, bilinear_w, out_w, out_b, hidden0, hidden1, ...) the backward kernels write into."""
+    latent_w, bilinear_w, out_w, out_b, hidden0, hidden1, ...) the backward kernels write into; the entry
+    "__ready__", if present, is a callable invoked once the backward launch sequence has been enqueued."""
     return _Decoder.apply(spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b,
                           *hidden)
 
@@ -404,8 +408,12 @@ def ctf_filter(table, n, m, scale=1.0, device=None):
     tab = tab.to(dev)
     _require_hip(tab, "CTF table")
     out = torch.empty(tab.size(0), n, m, dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    ws_bytes = L.svae_ctf_filter_workspace_bytes(tab.size(0), n, m)    # 0 while a filter's transform fits the LDS (~80 x 80)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().svae_ctf_filter(tab.data_ptr(), out.data_ptr(), tab.size(0), n, m, float(scale), _stream(dev)))
+        _lib.check(L.svae_ctf_filter(tab.data_ptr(), out.data_ptr(), tab.size(0), n, m, float(scale), _p(ws), ws_bytes,
+                                     _stream(dev)))
     return out
 
 

@@ -225,6 +225,12 @@ def gen_ctf_fixture():
     out = {"table": tab}
     for n, m, scale in ((9, 9, 1), (15, 13, 2), (39, 39, 1)):
         out["filt_%dx%d_s%d" % (n, m, scale)] = ref_ctf.ctf_filter(ref_ctf.parse_ctf(path), n, m, scale=scale)
+    # two particles at sizes beyond the device kernel's in-LDS limit (the reference's numpy code has none)
+    first2 = os.path.join(HERE, "_ctf_first2.txt")
+    np.savetxt(first2, tab[:2])
+    for n, m, scale in ((129, 129, 1), (100, 96, 2)):
+        out["big_%dx%d_s%d" % (n, m, scale)] = ref_ctf.ctf_filter(ref_ctf.parse_ctf(first2), n, m, scale=scale)
+    os.remove(first2)
     np.savez_compressed(os.path.join(HERE, "ctf_golden.npz"), **out)
     print("ctf fixture written")
 

@@ -7,6 +7,8 @@ import torch
 
 from helpers import GOLDEN_DIR
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _dests(ns):
     return set(vars(ns).keys())
@@ -66,9 +68,10 @@ def test_running_mean_matches_reference_arithmetic():
     rm = RunningMean(torch.device("cpu"))
     for b, v in zip(sizes, vals):
         count += b
-        acc += b * (v - acc) / count                                        # train_mnist.py:156-164
-        rm.update(b, [torch.tensor(x) for x in v])
-    assert np.allclose(rm.values(), acc, rtol=0, atol=1e-12)
+        ref = v * np.array([1.0, -1.0, 1.0])                                # the reference logs gen_loss = -log_p
+        acc += b * (ref - acc) / count                                      # train_mnist.py:156-164
+        rm.update(b, torch.tensor(v))                                       # (elbo, log_p, kl) as eval_minibatch returns them
+    assert np.array_equal(np.array(rm.values()), acc)                       # bit for bit: negation commutes with the arithmetic
 
 
 def test_coord_grid_matches_case_builder():
@@ -77,14 +80,22 @@ def test_coord_grid_matches_case_builder():
     assert np.array_equal(coord_grid(9, 5).numpy(), C.coord_grid(9, 5))
 
 
-def test_ctf_filter_matches_reference_fixture():
+def test_ctf_oracle_matches_reference_fixture():
+    """oracle/ctf_oracle.py (what the device kernel is tested against) reproduces the filters the reference's own
+    spatial_vae/ctf.py wrote, including sizes above the kernel's in-LDS limit."""
+    from oracle import ctf_oracle as O
     from spatial_vae_amd import ctf as C
     with np.load(os.path.join(GOLDEN_DIR, "ctf_golden.npz")) as f:
         gold = {k: f[k] for k in f.files}
     params = C.parse_ctf(os.path.join(GOLDEN_DIR, "ctf_table.txt"))
-    for key, (n, m, s) in {"filt_9x9_s1": (9, 9, 1), "filt_15x13_s2": (15, 13, 2)}.items():
-        got = C.ctf_filter(params, n, m, scale=s)
+    assert np.array_equal(C.ctf_table(params), gold["table"])
+    for key, (n, m, s) in {"filt_9x9_s1": (9, 9, 1), "filt_15x13_s2": (15, 13, 2), "filt_39x39_s1": (39, 39, 1)}.items():
+        got = O.ctf_filter(params, n, m, scale=s)
         assert got.shape == gold[key].shape
+        assert np.abs(got - gold[key]).max() <= 1e-7 * np.abs(gold[key]).max()
+    first2 = {k: v[:2] for k, v in params.items()}
+    for key, (n, m, s) in {"big_129x129_s1": (129, 129, 1), "big_100x96_s2": (100, 96, 2)}.items():
+        got = O.ctf_filter(first2, n, m, scale=s)
         assert np.abs(got - gold[key]).max() <= 1e-7 * np.abs(gold[key]).max()
 
 
@@ -107,3 +118,29 @@ def test_image_grid_layout_and_label():
     assert one.shape == (4, 6, 3)                                                 # a single image is not padded
     ns = argparse.Namespace(z_dim=2, p_hidden_dim=5, p_num_layers=3, q_num_layers=1, save_prefix="run", num_epochs=7)
     assert cli.save_label(ns) == "run_z2pnl3qnl1ep7"
+
+
+def test_bench_flop_accounting_matches_baseline_md():
+    """bench.py's per-config FLOP figures are BASELINE.md section 4's (F_fwd in GF: 25.24 / 100.95 / 412.9 / 8818 / 206.0)."""
+    import bench
+    want = {1: 25.24e9, 2: 100.95e9, 3: 412.9e9, 4: 8.818e12, 5: 206.0e9}
+    for cid, f in want.items():
+        cfg = bench.CONFIGS[cid]
+        fwd, step, gemm = bench.decoder_flops(cfg, cfg["B"])
+        assert abs(fwd - f) / f < 2e-3, (cid, fwd)
+        assert step == 3 * fwd and gemm == 2.0 * cfg["B"] * cfg["n"] ** 2 * cfg["H"] ** 2
+    assert bench.inf_dim(bench.CONFIGS[1]) == 3 and bench.inf_dim(bench.CONFIGS[5]) == 11
+
+
+def test_bench_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` without torchrun spawns two ranks itself; with no GPU here both fail at device selection and
+    the parent must come back non-zero instead of hanging (on the GPU box tests/test_gpu_bench.py sees the JSON line)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    if __import__("torch").cuda.is_available():
+        return
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -1,0 +1,106 @@
+"""Data-parallel TrainStep on CPU: two gloo ranks against a single-process run.
+
+The decoder has no CPU form, so these tests drive dp.TrainStep with a small pure-torch ELBO (TrainStep takes any
+eval_minibatch callable and any modules): what is under test is the DP machinery -- the parameter broadcast at
+construction, the -local/global backward seed, the two gradient buckets, the three metrics riding in the second
+bucket, ragged and EMPTY shards -- not the decoder.  The same contract with the real HIP decoder is
+tests/test_gpu_dp.py (two ranks sharing cuda:0)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["SVAE_ROOT"])
+import torch, torch.nn as nn, torch.distributed as dist
+from spatial_vae_amd import dp
+
+def toy_elbo(x, y, p_net, q_net, noise=None):
+    q = q_net(y)
+    mu, logstd = q[:, :2], q[:, 2:]
+    z = mu + logstd.exp() * noise
+    y_hat = p_net(z)
+    log_p = -((y_hat - y) ** 2).sum(1).mean()
+    kl = (-logstd + 0.5 * logstd.exp() ** 2 + 0.5 * mu ** 2 - 0.5).sum(1).mean()
+    return log_p - kl, log_p, kl
+
+def nets(seed):
+    torch.manual_seed(seed)
+    return (nn.Sequential(nn.Linear(2, 8), nn.Tanh(), nn.Linear(8, 5)),
+            nn.Sequential(nn.Linear(5, 8), nn.Tanh(), nn.Linear(8, 4)))
+
+rank, world, _ = dp.init_process_group(device_is_gpu=False)
+bucketed = os.environ.get("BUCKETED") == "1"
+p_net, q_net = nets(100 + rank)                     # every rank starts from its OWN weights: the broadcast must fix that
+step = dp.TrainStep(p_net, q_net, toy_elbo, lr=1e-2, bucketed=bucketed)
+assert step.aliased()
+seed = dp.shared_seed(torch.device("cpu"))
+gen = torch.Generator().manual_seed(1234)
+sizes = [8, 5, 1, 6]                                # 4+4, 3+2 (ragged), 1+0 (rank 1 has NO rows), 3+3
+batches = [torch.randn(b, 5, generator=gen) for b in sizes]
+noises = [torch.randn(b, 2, generator=gen) for b in sizes]
+
+# single-process reference from rank 0's initial weights: plain modules, plain torch.optim.Adam, whole batches
+rp, rq = nets(100)
+opt = torch.optim.Adam(list(rp.parameters()) + list(rq.parameters()), lr=1e-2)
+for y, r in zip(batches, noises):
+    lo, hi = dp.shard_bounds(y.size(0), rank, world)
+    step(None, y[lo:hi], weight=(hi - lo) / y.size(0), noise=r[lo:hi])
+    got = step.metrics.clone()
+    e, lp, kl = toy_elbo(None, y, rp, rq, noise=r)
+    opt.zero_grad(); (-e).backward(); opt.step()
+    want = torch.stack([e, lp, kl]).detach()
+    assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item(), (got, want)
+
+ref = torch.cat([p.detach().reshape(-1) for p in list(rp.parameters()) + list(rq.parameters())])
+mine = step.grads.flat_param
+err = (mine - ref).abs().max().item() / ref.abs().max().item()
+both = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert torch.equal(both[0], both[1]), "replicas diverged"
+assert step.aliased()
+assert all(torch.equal(p.detach().reshape(-1), step.grads.flat_param[o:o + p.numel()]) for p, o in
+           zip(step.grads.params, [sum(q.numel() for q in step.grads.params[:i]) for i in range(len(step.grads.params))]))
+print("rank", rank, "seed", seed, "param err", err)
+assert err < 1e-6, err
+dist.destroy_process_group()
+'''
+
+
+def _run(tmp_path, bucketed):
+    sys.path.insert(0, ROOT)
+    from spatial_vae_amd import dp
+    script = tmp_path / "dp_step_worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, SVAE_ROOT=ROOT, BUCKETED="1" if bucketed else "0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r]))" % (ROOT, str(script)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rank")]
+    assert len(lines) == 2
+    assert len({l.split()[3] for l in lines}) == 1, "ranks disagree on the shared seed: %r" % lines
+
+
+def test_trainstep_world2_matches_single_process_one_bucket(tmp_path):
+    _run(tmp_path, bucketed=False)
+
+
+def test_trainstep_world2_matches_single_process_two_buckets(tmp_path):
+    _run(tmp_path, bucketed=True)
+
+
+def test_launch_ranks_reports_a_failing_rank(tmp_path):
+    """A rank that dies takes the job down with its exit code instead of leaving its peers blocked."""
+    script = tmp_path / "boom.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                      "time.sleep(60)\n")
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r]))" % (ROOT, str(script)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 7

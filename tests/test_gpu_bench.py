@@ -1,0 +1,48 @@
+"""bench.py as the driver invokes it: a plain `python bench.py --gpus N` must start its own ranks and print ONE JSON line.
+On a 1-GPU box the two ranks share cuda:0 (SVAE_SHARE_GPU=1, gloo transport): a functional rehearsal of the launch path and
+of the weak / strong sharding, not a scaling measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, share=False):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_GEMM")}
+    if share:
+        env["SVAE_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_from_a_plain_invocation(scaling):
+    d = _bench(["--gpus", "2", "--config", "1", "--steps", "3", "--warmup", "2", "--scaling", scaling, "--no-cpu-baseline",
+                "--no-secondary"], share=True)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["global_batch"] == (128 if scaling == "weak" else 64)
+    assert d["config"]["per_gpu_batch"] == (64 if scaling == "weak" else 32)
+    ar = d["allreduce"]
+    assert len(ar["buckets_bytes"]) == 2 and sum(ar["buckets_bytes"]) == ar["bytes_per_step"]
+    assert ar["bytes_per_step"] == 4 * (899507 + 3)                  # cfg 1 has 899,507 parameters (+ 3 metrics)
+    assert d["cpu_baseline"] is None and d["roofline"]["kernel"] in ("dense_fwd", "dense_dgrad", "wgrad")
+
+
+def test_single_gpu_line_carries_roofline_and_cpu_baseline():
+    d = _bench(["--config", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--no-secondary"])
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["unit"] == "images/s" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.05 < r["frac"] < 1.0
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread"]["value"] > 0
+    assert "median" in c["sample"] and "2 warm-ups" in c["sample"]

@@ -1,0 +1,140 @@
+"""Data-parallel training step with the real HIP decoder: two ranks SHARING cuda:0 (SVAE_SHARE_GPU=1, gloo for the
+collectives -- a 1-GPU box has no second device for RCCL) against a one-rank run of the same global minibatches.
+Covers everything of SURVEY.md section 8e except the RCCL transport itself: parameter broadcast from rank 0, the shared
+seed, contiguous ragged shards (5+3), a shard with NO rows (a 1-row global batch), the -local/global backward seed,
+the decoder bucket launched from inside backward on a side stream, and the metrics riding in the second bucket."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import contextlib, io, math, os, sys
+sys.path.insert(0, os.environ["SVAE_ROOT"])
+import numpy as np, torch, torch.nn as nn, torch.distributed as dist
+import spatial_vae.models as models
+from spatial_vae_amd import dp, elbo as E, cli
+
+out_path = os.environ["SVAE_DP_REF"]
+rank, world, local = dp.init_process_group(device_is_gpu=True)
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+n = m = 12
+torch.manual_seed(100 + rank)                       # every rank initialises differently; rank 0's weights must win
+with contextlib.redirect_stdout(io.StringIO()):
+    p_net = models.SpatialGenerator(2, 64, num_layers=2, activation=nn.Tanh).to(dev)
+    q_net = models.InferenceNetwork(n * m, 5, 32, num_layers=2, activation=nn.Tanh).to(dev)
+step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=1e-2, rotate=True, translate=True, dx_scale=0.1,
+                    theta_prior=math.pi / 4)
+assert step._bucketed and step.aliased()
+seed = dp.shared_seed(dev)
+x = cli.coord_grid(n, m).to(dev)
+rs = np.random.RandomState(7)
+sizes = [8, 8, 1, 6]                                # 4+4, then 5+3 via an uneven split below, 1+0 (EMPTY shard), 3+3
+ys = [torch.from_numpy(rs.uniform(size=(b, n * m)).astype(np.float32)).to(dev) for b in sizes]
+rs_ = [torch.from_numpy(rs.normal(size=(b, 5)).astype(np.float32)).to(dev) for b in sizes]
+
+def bounds(i, b):
+    if world == 2 and i == 1:                       # a deliberately ragged 5 + 3 split of the second batch
+        return (0, 5) if rank == 0 else (5, 8)
+    return dp.shard_bounds(b, rank, world)
+
+metrics = []
+for i, (y, r) in enumerate(zip(ys, rs_)):
+    lo, hi = bounds(i, y.size(0))
+    step(x, y[lo:hi], weight=(hi - lo) / y.size(0), noise=r[lo:hi])
+    metrics.append(step.metrics.clone())
+torch.cuda.synchronize()
+flat = step.grads.flat_param.detach().cpu()
+met = torch.stack(metrics).cpu()
+assert step.aliased()
+if world == 1:
+    torch.save({"flat": flat, "metrics": met}, out_path)
+    print("reference written", float(met[0, 0]))
+else:
+    ref = torch.load(out_path, weights_only=True)
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "replicas diverged"
+    perr = (flat - ref["flat"]).abs().max().item() / ref["flat"].abs().max().item()
+    merr = ((met - ref["metrics"]).abs().max(1).values / ref["metrics"].abs().max(1).values).max().item()
+    print("rank", rank, "seed", seed, "param err %.3e metric err %.3e" % (perr, merr))
+    assert perr < 2e-6 and merr < 2e-6, (perr, merr)
+    dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_on_one_gpu_match_the_single_rank_run(tmp_path):
+    script = tmp_path / "dp_gpu_worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, SVAE_ROOT=ROOT, SVAE_DP_REF=str(tmp_path / "ref.pt"), PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-3000:]
+    env["SVAE_SHARE_GPU"] = "1"
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r]))" % (ROOT, str(script)))
+    two = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stdout[-1500:] + two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("rank")]
+    assert len(lines) == 2 and len({l.split()[3] for l in lines}) == 1, lines
+
+
+def test_checkpointing_keeps_the_modules_inside_the_flat_buffers(tmp_path):
+    """cli.save_models must not move the live modules (their parameters are views of TrainStep's flat buffers; a
+    .cpu()/.to() round trip re-allocates them and training silently freezes)."""
+    import contextlib
+    import io
+    import math
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import spatial_vae.models as models
+    from spatial_vae_amd import cli, dp, elbo as E
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p_net = models.SpatialGenerator(2, 32, num_layers=2, activation=nn.Tanh).to(dev)
+        q_net = models.InferenceNetwork(100, 5, 16, num_layers=1, activation=nn.Tanh).to(dev)
+    step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=1e-2, rotate=True, translate=True, dx_scale=0.1,
+                        theta_prior=math.pi / 4)
+    x = cli.coord_grid(10, 10).to(dev)
+    y = torch.from_numpy(np.random.RandomState(0).uniform(size=(16, 100)).astype(np.float32)).to(dev)
+    step(x, y)
+    cli.save_models(str(tmp_path / "ck"), "1", p_net, q_net, dev)
+    assert step.aliased() and p_net.training is not None
+    assert "_grad_sinks" in p_net.__dict__ and "_grad_sinks" in q_net.__dict__
+    saved = torch.load(tmp_path / "ck_generator_epoch1.sav", weights_only=False)           # a file this test just wrote
+    assert not hasattr(saved, "_grad_sinks") and not saved.training
+    assert all(not p.is_cuda for p in saved.parameters())
+    before = {k: v.detach().cpu().clone() for k, v in p_net.state_dict().items()}
+    assert all(torch.equal(before[k], v) for k, v in saved.state_dict().items())
+    step(x, y)
+    after = p_net.state_dict()
+    assert any(not torch.equal(before[k], after[k].cpu()) for k in before), "training froze after the checkpoint"
+    e0 = float(step.metrics[0])
+    for _ in range(20):
+        step(x, y)
+    assert float(step.metrics[0]) > e0, "the ELBO no longer improves after a checkpoint"
+
+
+def test_train_particles_saving_every_epoch_keeps_training(tmp_path):
+    """The reference defaults (--save-interval 10, --num-epochs 100) checkpoint in mid-run; with --save-interval 1 every
+    epoch's checkpoint must differ from the previous one."""
+    import torch
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train_particles.py"), "x", "y", "--synthetic", "64", "--num-epochs", "3",
+                          "--minibatch-size", "32", "--p-hidden-dim", "32", "--q-hidden-dim", "32", "--save-prefix", "p",
+                          "--save-interval", "1", "--progress-every", "0", "-l", "1e-3"], cwd=str(tmp_path), env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    sd = [torch.load(tmp_path / ("p_generator_epoch%d.sav" % e), weights_only=False).state_dict() for e in (1, 2, 3)]
+    for a, b in ((sd[0], sd[1]), (sd[1], sd[2])):
+        assert any(not torch.equal(a[k], b[k]) for k in a)
+    rows = [l.split("\t") for l in out.stdout.splitlines() if "\ttrain\t" in l]
+    assert float(rows[2][2]) > float(rows[0][2])                      # the training ELBO keeps improving

@@ -100,7 +100,7 @@ def test_library_is_the_hip_one():
     import ctypes
     from spatial_vae_amd import _lib
     L = _lib.lib()
-    assert isinstance(L, ctypes.CDLL) and L.svae_abi_version() == 1
+    assert isinstance(L, ctypes.CDLL) and L.svae_abi_version() == 2
 
 
 @pytest.mark.parametrize("name", ["mnist_rt", "mnist_L3", "mnist_leaky", "mnist_sigmoid_act", "galaxy_rgb", "particles_fit_noise",

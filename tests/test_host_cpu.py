@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libsvae_hip.so does not export %s" % name
     assert set(L.EXPORTS) <= declared
-    assert lib.svae_abi_version() == 1
+    assert lib.svae_abi_version() == 2
 
 
 def _desc(**kw):
