@@ -214,3 +214,104 @@ def sample_idx(size, count=4096):
     if size <= count:
         return np.arange(size)
     return np.linspace(0, size - 1, count).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Training-LOOP fixtures (tests/golden/gen_epoch_golden.py runs the reference's own train_epoch:
+# train_mnist.py:127-171, train_particles.py:151-202) and --vanilla fixtures (VanillaGenerator through
+# eval_minibatch: models.py:135-172, train_mnist.py:351-357, train_particles.py:446-452).
+# An epoch case = a decoder/encoder case + the minibatch sizes of each epoch (a ragged last batch on purpose), the
+# z_scale of each epoch (--z-delay: 0 for the first epochs, train_particles.py:500-504) and the Adam learning rate.
+def _epoch(name, base, batches, z_scales=(1,), lr=1e-3):
+    case = dict(base, name=name)
+    return dict(name=name, case=case, batches=tuple(batches), z_scales=tuple(z_scales), lr=lr)
+
+
+EPOCH_CASES = [
+    _epoch("epoch_mnist", _case("_", n=7, m=7, H=20, L=2, seed=60), batches=(4, 4, 3)),
+    _epoch("epoch_particles_zdelay", _case("_", script="particles", n=6, m=6, z_dim=3, H=24, L=2, theta_prior=np.pi, seed=61),
+           batches=(5, 5, 2), z_scales=(0, 1)),
+    _epoch("epoch_particles_ctf_mask", _case("_", script="particles", n=8, m=8, z_dim=2, H=24, L=3, ctf=True, mask=True,
+                                               theta_prior=np.pi, seed=62), batches=(6, 3)),
+]
+EPOCH_CASES_BY_NAME = {e["name"]: e for e in EPOCH_CASES}
+
+
+def build_epoch_inputs(ec):
+    """Initial parameters, the per-epoch minibatches (and CTF filters) and the noise of every step."""
+    case = ec["case"]
+    rs = np.random.RandomState(2000 + case["seed"])
+    n, m = case["n"], case["m"]
+    N = n * m
+    out = dict(x_coord=coord_grid(n, m), p_state=generator_state(case, rs), q_state=inference_state(case, rs),
+               mask=circular_mask(n, m) if case["mask"] else None)
+    total = sum(ec["batches"])
+    if case["script"] == "mnist":
+        u = rs.uniform(size=(total, N))
+        y = np.floor(u * (rs.uniform(size=(total, N)) > 0.6) * 255.0) / 255.0
+    else:
+        y = rs.normal(size=(total, N))
+    out["y"] = y.astype(np.float32)
+    if case["ctf"]:
+        k = n - 1 if n % 2 == 0 else n
+        f = rs.normal(size=(total, 1, k, k)) / k
+        f[:, 0, k // 2, k // 2] += 1.0
+        out["ctf"] = f.astype(np.float32)
+    else:
+        out["ctf"] = None
+    # one noise tensor per step: epochs x minibatches
+    out["r"] = [[rs.normal(size=(b, inf_dim(case))).astype(np.float32) for b in ec["batches"]] for _ in ec["z_scales"]]
+    return out
+
+
+def _vanilla(name, script="mnist", n=6, m=6, B=5, z_dim=3, H=20, L=2, act="tanh", n_out=1, softplus=False, resid=False,
+             q_hidden=24, q_layers=1, theta_prior=np.pi, mask=False, seed=0):
+    return dict(name=name, script=script, n=n, m=m, B=B, z_dim=z_dim, H=H, L=L, act=act, n_out=n_out, softplus=softplus,
+                resid=resid, q_hidden=q_hidden, q_layers=q_layers, theta_prior=float(theta_prior), mask=mask, seed=seed,
+                rotate=False, translate=False, dx_scale=0.1, z_scale=1.0, expand_coords=False, bilinear=False, ctf=False,
+                wscale=1.0, store="full", augment=False)
+
+
+VANILLA_CASES = [
+    _vanilla("vanilla_mnist", seed=70),                                                        # train_mnist.py --vanilla
+    _vanilla("vanilla_mnist_leaky_L3", L=3, act="leakyrelu", seed=71),
+    _vanilla("vanilla_particles", script="particles", seed=72),                                # Gaussian, unit variance
+    _vanilla("vanilla_particles_softplus_noise", script="particles", n_out=2, softplus=True, resid=True, L=3, mask=True,
+             seed=73),                                                                         # --fit-noise --softplus --resid
+]
+VANILLA_CASES_BY_NAME = {c["name"]: c for c in VANILLA_CASES}
+
+
+def vanilla_state(case, rs):
+    """Parameters of VanillaGenerator in construction order (models.py:146-157)."""
+    H, L, zd = case["H"], case["L"], case["z_dim"]
+    st = OrderedDict()
+    w, b = _linear(rs, H, zd, 1.0)
+    st["layers.0.weight"], st["layers.0.bias"] = w, b
+    idx = 2
+    for _ in range(1, L):
+        w, b = _linear(rs, H, H, 1.0)
+        if case["resid"]:
+            st["layers.%d.linear.weight" % idx], st["layers.%d.linear.bias" % idx] = w, b
+            idx += 1
+        else:
+            st["layers.%d.weight" % idx], st["layers.%d.bias" % idx] = w, b
+            idx += 2
+    w, b = _linear(rs, case["n"] * case["m"] * case["n_out"], H, 1.0)
+    st["layers.%d.weight" % idx], st["layers.%d.bias" % idx] = w, b
+    return st
+
+
+def build_vanilla_inputs(case):
+    rs = np.random.RandomState(3000 + case["seed"])
+    n, m, B = case["n"], case["m"], case["B"]
+    N = n * m
+    out = dict(x_coord=coord_grid(n, m), p_state=vanilla_state(case, rs), q_state=inference_state(case, rs),
+               mask=circular_mask(n, m) if case["mask"] else None)
+    if case["script"] == "mnist":
+        y = np.floor(rs.uniform(size=(B, N)) * (rs.uniform(size=(B, N)) > 0.6) * 255.0) / 255.0
+    else:
+        y = rs.normal(size=(B, N))
+    out["y"] = y.astype(np.float32)
+    out["r"] = rs.normal(size=(B, case["z_dim"])).astype(np.float32)
+    return out

@@ -108,3 +108,61 @@ def test_torch_cpu_step_siblings_match_reference(name):
     assert abs(out[1].item() - float(gold["log_p"])) <= TOL * abs(float(gold["log_p"]))
     check_grads("gp.", {k: v.grad.numpy() for k, v in pp.items()}, gold, case, 5 * TOL)
     check_grads("gq.", {k: v.grad.numpy() for k, v in qp.items()}, gold, case, 5 * TOL)
+
+
+@pytest.mark.parametrize("name", [e["name"] for e in C.EPOCH_CASES])
+def test_torch_cpu_trainer_reproduces_reference_epochs(name):
+    """CpuTrainer (what bench.py times as cpu_baseline) stepped over the reference's train_epoch fixtures: every step's
+    (elbo, log_p, kl) and every parameter after the last Adam update (train_mnist.py:127-171, train_particles.py:151-202,
+    incl. the --z-delay schedule)."""
+    import torch
+    from oracle import torch_cpu_step as T
+    ec = C.EPOCH_CASES_BY_NAME[name]
+    case = ec["case"]
+    inp = C.build_epoch_inputs(ec)
+    gold = load_golden(name)
+    kw = dict(act=case["act"], rotate=case["rotate"], translate=case["translate"], dx_scale=case["dx_scale"],
+              theta_prior=case["theta_prior"])
+    tr = T.CpuTrainer(inp["p_state"], inp["q_state"], inp["x_coord"], lr=ec["lr"], script=case["script"], **kw)
+    bounds = np.cumsum((0,) + ec["batches"])
+    y = torch.from_numpy(inp["y"])
+    got = []
+    for e, zs in enumerate(ec["z_scales"]):
+        for i in range(len(ec["batches"])):
+            sl = slice(int(bounds[i]), int(bounds[i + 1]))
+            batch = {}
+            if case["script"] == "particles":
+                batch = dict(z_scale=zs, mask=torch.from_numpy(inp["mask"]) if inp["mask"] is not None else None,
+                             ctf=torch.from_numpy(inp["ctf"][sl]) if inp["ctf"] is not None else None)
+            got.append([float(v) for v in tr.step(y[sl], torch.from_numpy(inp["r"][e][i]), **batch)])
+    got = np.array(got)
+    assert np.abs(got - gold["steps"]).max() <= TOL * np.abs(gold["steps"]).max()
+    for k, v in tr.pp.items():
+        assert rel_err(v.detach().numpy(), gold["p." + k]) < 1e-4, k
+    for k, v in tr.qp.items():
+        assert rel_err(v.detach().numpy(), gold["q." + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in C.VANILLA_CASES if c["script"] == "mnist"])
+def test_vanilla_generator_mirror_matches_reference_on_cpu(name):
+    """spatial_vae.models.VanillaGenerator (plain torch, so it runs here): state-dict names and y_hat of the reference's
+    --vanilla eval_minibatch (models.py:135-172)."""
+    import torch
+    import torch.nn as nn
+    import spatial_vae.models as models
+    case = C.VANILLA_CASES_BY_NAME[name]
+    inp = C.build_vanilla_inputs(case)
+    gold = load_golden(name)
+    act = {"tanh": nn.Tanh, "leakyrelu": nn.LeakyReLU}[case["act"]]
+    p = models.VanillaGenerator(case["n"] * case["m"], case["z_dim"], case["H"], n_out=case["n_out"], num_layers=case["L"],
+                                activation=act, softplus=case["softplus"], resid=case["resid"])
+    q = models.InferenceNetwork(case["n"] * case["m"], case["z_dim"], case["q_hidden"], num_layers=case["q_layers"], activation=act,
+                                resid=case["resid"])
+    assert list(p.state_dict().keys()) == list(inp["p_state"].keys())
+    p.load_state_dict({k: torch.from_numpy(v) for k, v in inp["p_state"].items()})
+    q.load_state_dict({k: torch.from_numpy(v) for k, v in inp["q_state"].items()})
+    with torch.no_grad():
+        mu, logstd = q(torch.from_numpy(inp["y"]))
+        z = torch.exp(logstd) * torch.from_numpy(inp["r"]) + mu
+        y_hat = p(torch.from_numpy(inp["x_coord"]), z).view(case["B"], -1)
+    assert rel_err(y_hat.numpy(), gold["y_hat"]) < TOL
