@@ -36,6 +36,21 @@ def test_train_mnist_cli(tmp_path):
     assert type(p).__name__ == "SpatialGenerator" and "coord_linear.weight" in p.state_dict()
 
 
+def test_vanilla_flag_on_the_command_lines(tmp_path):
+    """--vanilla (train_mnist.py:351-357, train_particles.py:446-452): VanillaGenerator, no pose inference."""
+    rows = _run("train_mnist.py", ["--synthetic", "128", "--num_epochs", "2", "--minibatch_size", "32", "--p_hidden_dim", "32",
+                                   "--q_hidden_dim", "32", "--vanilla", "--save_prefix", "v", "--progress_every", "0", "-l", "1e-3"],
+                str(tmp_path))
+    vals = [[float(x) for x in r.split("\t")] for r in rows[1:]]
+    assert len(vals) == 4 and all(np.isfinite(v).all() for v in vals) and vals[2][1] > vals[0][1]
+    p = torch.load(tmp_path / "outputs_v" / "trained" / "v_generator_epoch2.sav", weights_only=False)   # written just now
+    assert type(p).__name__ == "VanillaGenerator"
+    rows = _run("train_particles.py", ["x", "y", "--synthetic", "64", "--num-epochs", "1", "--minibatch-size", "32", "--p-hidden-dim",
+                                       "32", "--q-hidden-dim", "32", "--vanilla", "--fit-noise", "--softplus", "--progress-every", "0"],
+                str(tmp_path))
+    assert len(rows) == 3 and all(np.isfinite([float(v) for v in r.split("\t")[2:]]).all() for r in rows[1:])
+
+
 def test_train_galaxy_cli(tmp_path):
     rows = _run("train_galaxy.py", ["x", "y", "--synthetic", "64", "--num_epochs", "1", "--minibatch_size", "32", "--p_hidden_dim", "32",
                                     "--q_hidden_dim", "32", "--p_num_layers", "3", "-z", "4", "--save_prefix", "g", "--progress_every",

@@ -18,9 +18,10 @@ from oracle import elbo_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-# (name, script, n, B, z_dim, H, L, n_out, extra): BASELINE.json configs 2, 3, 4 (reduced batch: the
+# (name, script, n, B, z_dim, H, L, n_out, extra): BASELINE.json configs 1 (rotate only), 2, 3, 4 (reduced batch: the
 # oracle needs B*N*H*4 bytes per activation plane on the host), 5
 FULL = [
+    ("cfg1_mnist_r_B64", dict(script="mnist", n=28, m=28, B=64, z_dim=2, H=500, L=2, translate=False, theta_prior=math.pi / 4)),
     ("cfg2_mnist_rt_B256", dict(script="mnist", n=28, m=28, B=256, z_dim=2, H=500, L=2, theta_prior=math.pi / 4)),
     ("cfg3_5hdb_noise_B64", dict(script="particles", n=40, m=40, B=64, z_dim=2, H=500, L=2, n_out=2, theta_prior=math.pi)),
     ("cfg4_galaxy_B2", dict(script="galaxy", n=128, m=128, B=2, z_dim=20, H=1024, L=3, n_out=3, theta_prior=math.pi)),
@@ -48,8 +49,8 @@ def _run_gpu(case, inp):
     x = torch.from_numpy(inp["x_coord"]).to(dev)
     y = torch.from_numpy(inp["y"]).to(dev)
     r = torch.from_numpy(inp["r"]).to(dev)
-    kw = dict(rotate=True, translate=True, dx_scale=case["dx_scale"], theta_prior=case["theta_prior"], noise=r,
-              return_logits=True)
+    kw = dict(rotate=case["rotate"], translate=case["translate"], dx_scale=case["dx_scale"], theta_prior=case["theta_prior"],
+              noise=r, return_logits=True)
     if case["script"] == "mnist":
         elbo, log_p, kl, _, logits = E.eval_minibatch_mnist(x, y, p_net, q_net, **kw)
     elif case["script"] == "galaxy":
@@ -71,8 +72,8 @@ def test_full_size_matches_oracle(name, kw):
     inp = C.build_inputs(case)
     elbo, log_p, kl, logits, grads, q_out, _ = _run_gpu(case, inp)
     ref = O.elbo_minibatch(case["script"], O.DecoderSpec.from_case(case), inp["p_state"], inp["x_coord"], inp["y"], q_out,
-                           inp["r"], rotate=True, translate=True, dx_scale=case["dx_scale"], theta_prior=case["theta_prior"],
-                           ctf=inp["ctf"])
+                           inp["r"], rotate=case["rotate"], translate=case["translate"], dx_scale=case["dx_scale"],
+                           theta_prior=case["theta_prior"], ctf=inp["ctf"])
     assert abs(elbo - float(ref["elbo"])) <= 1e-4 * abs(float(ref["elbo"]))
     assert abs(log_p - float(ref["log_p"])) <= 1e-4 * abs(float(ref["log_p"]))
     assert rel_err(logits, ref["logits"]) < 1e-4
