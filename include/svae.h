@@ -15,9 +15,11 @@
  *     hipStream_t; NULL = the default stream) and the call returns; 0 = success, a negative
  *     SVAE_E_* code otherwise, with text in svae_last_error() (thread-local);
  *   - the library is stateless and re-entrant: one process per GPU, any number of streams;
- *   - `saved` (svae_saved_bytes) carries activations from forward to backward and must stay
- *     untouched in between; `ws` (svae_workspace_bytes) is scratch, free to reuse after the
- *     call's work has completed on the stream.  Both must be 256-byte aligned.
+ *   - `saved` (svae_saved_bytes) carries activations (and the packed weights / per-image tables
+ *     built from the parameters, z and the pose) from forward to backward and must stay untouched
+ *     in between, as must the parameters, z and the pose themselves; `ws` (svae_workspace_bytes) is
+ *     scratch, free to reuse after the call's work has completed on the stream.  Both must be
+ *     256-byte aligned.
  */
 #ifndef SVAE_H
 #define SVAE_H
@@ -217,9 +219,10 @@ int svae_colsum(const float* x, int32_t rows, int32_t cols, float* out, svae_str
  *                      p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
  * `step` is t (1 for the first update).  ATen's fused multi-tensor kernel gives one flat tensor of 0.9 M
  * elements only 14 thread blocks (98 us on MI355X); this is a plain grid over the elements (~5 us).
+ * zero_grad != 0 also clears `grad` behind the update (optim.zero_grad(), train_mnist.py:150) in the same pass.
  */
-int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                   float beta2, float eps, int64_t step, svae_stream_t stream);
+int svae_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t step, int32_t zero_grad, svae_stream_t stream);
 
 /*
  * Rotation augmentation of the observed images before inference: the reference rotates each image of the

@@ -98,7 +98,7 @@ def lib():
     L.svae_colsum.argtypes = [vp, i32, i32, vp, vp]
     L.svae_adam_step.restype = ctypes.c_int
     L.svae_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                 ctypes.c_float, ctypes.c_int64, vp]
+                                 ctypes.c_float, ctypes.c_int64, i32, vp]
     L.svae_rotate_bicubic.restype = ctypes.c_int
     L.svae_rotate_bicubic.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.svae_ctf_filter.restype = ctypes.c_int

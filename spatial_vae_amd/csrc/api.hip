@@ -124,7 +124,17 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     Carver cs(saved);
     for (int l = 0; l < g.L; ++l) p.act[l] = cs.take<float>(MH);
     p.savedC = split_mode() ? cs.take<uint4>(MH / 4) : nullptr;  // fp16x3: column fragments of a0 for the weight gradient
-    p.saved_bytes = cs.off;
+    // what launch_prepare builds (packed weights, first-layer tables, poses: a few MB) also rides in `saved`, so the
+    // backward call does not rebuild it; inference-only calls (saved == NULL) keep it in the workspace
+    float* swf[SVAE_MAX_HIDDEN];
+    float* swb[SVAE_MAX_HIDDEN];
+    for (int l = 0; l + 1 < g.L; ++l) {
+        swf[l] = cs.take<float>((size_t)g.Hp * g.Hp);
+        swb[l] = cs.take<float>((size_t)g.Hp * g.Hp);
+    }
+    float* stab = cs.take<float>((size_t)g.B * g.Hp * kSlots);
+    float4* sposebuf = cs.take<float4>(g.B);
+    p.saved_bytes = (cs.off + 255) & ~size_t(255);
 
     p.wg_nblk1 = (g.ntile + 7) / 8;
     {
@@ -162,6 +172,14 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     }
     p.tab = cw.take<float>((size_t)g.B * g.Hp * kSlots);
     p.posebuf = cw.take<float4>(g.B);
+    if (saved) {
+        for (int l = 0; l + 1 < g.L; ++l) {
+            p.wf[l] = swf[l];
+            p.wb[l] = swb[l];
+        }
+        p.tab = stab;
+        p.posebuf = sposebuf;
+    }
     p.dh[0] = cw.take<float>(MH);
     p.dh[1] = cw.take<float>(MH);
     p.do_p = cw.take<float>((size_t)g.C * g.Mp);
@@ -564,11 +582,14 @@ void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, hipStream_t st) {
 template <int ACT>
 void launch_layer0_fwd(const Geo& g, const Plan& pl, const PoseArgs& pa, float* a0, hipStream_t st) {
     Scope prof(K_LAYER0_FWD, st);
-    const long ngroups = (long)g.B * ((g.Npad / 8 + kL0Group - 1) / kL0Group);
-    const unsigned gy = (unsigned)(ngroups < 32768 ? ngroups : 32768);
-    const unsigned gz = (unsigned)((ngroups + gy - 1) / gy);
+    const int oimg = g.Npad / 8;
+    const int cpi = (oimg + kL0Chunk - 1) / kL0Chunk;   // chunks per image, evenly sized
+    const int opc = (oimg + cpi - 1) / cpi;
+    const long nchunks = (long)g.B * cpi;
+    const unsigned gy = (unsigned)(nchunks < 32768 ? nchunks : 32768);
+    const unsigned gz = (unsigned)((nchunks + gy - 1) / gy);
     hipLaunchKernelGGL((layer0_fwd_kernel<ACT>), dim3(blocks_for(g.Hp * 2), gy, gz), dim3(256), 0, st, pa, pl.posebuf,
-                       pl.tab, a0, row_geo(g), ngroups);
+                       pl.tab, a0, row_geo(g), opc, (oimg + opc - 1) / opc, nchunks);
 }
 
 template <int ACT>
@@ -713,8 +734,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     hipStream_t st = static_cast<hipStream_t>(stream);
     const PoseArgs pa = pose_args(pose);
     const int resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
-
-    launch_prepare(g, pl, p, pa, z, st);
+    // the packed weights, first-layer tables and poses were left in `saved` by the forward call (make_plan)
     // fp16x3: the data gradient of the last hidden layer runs on the f16 pipe (bounded act', contraction multiple of 64)
     const char* fuse_env0 = getenv("SVAE_FUSE_OUT");
     const bool split_bwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0 &&
@@ -723,10 +743,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     // d(loss)/d(logits) in padded row space (pad rows exactly zero)
     {
         Scope prof(K_DLOGITS, st);
-        if (hipMemsetAsync(pl.do_p, 0, (size_t)g.C * g.Mp * sizeof(float), st) != hipSuccess)
-            return fail(SVAE_E_LAUNCH, "memset failed");
         if (split_bwd && hipMemsetAsync(pl.amax, 0, sizeof(unsigned), st) != hipSuccess) return fail(SVAE_E_LAUNCH, "memset failed");
-        hipLaunchKernelGGL(dlogits_kernel, dim3(blocks_for((long)g.B * g.N * g.C)), dim3(256), 0, st, logits, dy, dy_scale,
+        hipLaunchKernelGGL(dlogits_kernel, dim3(blocks_for((long)g.C * g.Mp)), dim3(256), 0, st, logits, dy, dy_scale,
                            pl.do_p, g.B, g.N, g.Npad, g.C, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp,
                            split_bwd ? pl.amax : (unsigned*)nullptr);
         if (split_bwd)
@@ -796,7 +814,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             }
             Scope prof(K_WGRAD_REDUCE, st);
             const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for((long)g.H * g.H)), dim3(256), 0, st, pl.slab, pl.bslab,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)g.H * g.H + 63) / 64)), dim3(256), 0, st, pl.slab, pl.bslab,
                                grads->hidden_w[l - 1], db_elsewhere ? (float*)nullptr : grads->hidden_b[l - 1], g.H, g.Hp,
                                pl.wg_S);
             if (db_elsewhere && grads->hidden_b[l - 1])
@@ -837,15 +855,16 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     float* dc = (pg && pg->dcoords) ? pg->dcoords : pl.dcoords;
     {
         Scope prof_l0(K_LAYER0_BWD, st);
+        const bool split_first = split_bwd && (g.L == 2 || split_chain_on());   // which kernel ran the FIRST epilogue
+        const bool want_dz = dz && g.Zd > 0;
         if (fused_first) {
-            // dh0 was reduced inside the data-gradient GEMM's epilogue: only small fixed-order sums remain
-            hipLaunchKernelGGL(sgtile_reduce_kernel, dim3(blocks_for((long)g.B * g.Hp)), dim3(256), 0, st, pl.sgtile, pl.sgimg,
-                               g.B, g.Hp, g.Timg);
-            if (want_coords)
-                hipLaunchKernelGGL(coords_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, dc,
-                                   g.ntile / ((split_bwd && (g.L == 2 || split_chain_on())) ? split_nt(g) : dense_nt_first(g.ntile)), g.B, g.N,
-                                   g.Npad,
-                                   (long)g.Mp);
+            // dh0 was reduced inside the data-gradient GEMM's epilogue: only small fixed-order per-image sums remain
+            hipLaunchKernelGGL(first_layer_image_kernel, dim3(g.B, want_coords ? 2 : 1), dim3(256), 0, st, pl.sgtile,
+                               split_first ? 2 : 1, g.Timg, g.H, g.Hp, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr,
+                               want_dz ? dz : (float*)nullptr, g.Zd, g.in_dim, pl.dfpart,
+                               g.ntile / (split_first ? split_nt(g) : dense_nt_first(g.ntile)), g.N, g.Npad, (long)g.Mp,
+                               want_coords ? dc : (float*)nullptr, pose->grid, pl.posebuf, pg ? pg->dtheta : (float*)nullptr,
+                               pg ? pg->ddx : (float*)nullptr);
         } else {
             const float* dh0 = pl.dh[cur];
             hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0,
@@ -862,12 +881,14 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         hipLaunchKernelGGL(layer0_param_grads_kernel, dim3((unsigned)(((long)g.H * kSlots + 31) / 32)), dim3(256), 0, st,
                            pl.sgimg, z, grads->coord_w, grads->coord_b, g.Zd > 0 ? grads->latent_w : nullptr,
                            bil ? grads->bilinear_w : nullptr, g.B, g.H, g.Hp, g.Zd, g.in_dim);
-        if (dz && g.Zd > 0)
-            hipLaunchKernelGGL(dz_kernel, dim3(g.B), dim3(256), 0, st, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr,
-                               dz, g.H, g.Hp, g.Zd, g.in_dim);
-        if (want_coords && (pg->dtheta || pg->ddx))
-            hipLaunchKernelGGL(pose_bwd_kernel, dim3(g.B), dim3(256), 0, st, dc, pose->grid, pl.posebuf, pg->dtheta, pg->ddx,
-                               g.N);
+        if (!fused_first) {
+            if (want_dz)
+                hipLaunchKernelGGL(dz_kernel, dim3(g.B), dim3(256), 0, st, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr,
+                                   dz, g.H, g.Hp, g.Zd, g.in_dim);
+            if (want_coords && (pg->dtheta || pg->ddx))
+                hipLaunchKernelGGL(pose_bwd_kernel, dim3(g.B), dim3(256), 0, st, dc, pose->grid, pl.posebuf, pg->dtheta, pg->ddx,
+                                   g.N);
+        }
     }
     return launch_status("svae_decoder_backward");
 }
@@ -985,8 +1006,8 @@ int svae_colsum(const float* x, int32_t rows, int32_t cols, float* out, svae_str
     return launch_status("svae_colsum");
 }
 
-int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                   float beta2, float eps, int64_t step, svae_stream_t stream) {
+int svae_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t step, int32_t zero_grad, svae_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return fail(SVAE_E_INVALID, "svae_adam_step: bad arguments");
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
@@ -995,7 +1016,7 @@ int svae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
     hipStream_t st = static_cast<hipStream_t>(stream);
     Scope prof(K_ADAM, st);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (long)n,
-                       (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, eps);
+                       (float)(lr / bc1), (float)sqrt(bc2), beta1, beta2, eps, zero_grad ? 1 : 0);
     return launch_status("svae_adam_step");
 }
 

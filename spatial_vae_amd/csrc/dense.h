@@ -49,7 +49,7 @@ struct DenseArgs {
     PoseArgs pose;
     const float4* posebuf;  // (B) cos, sin, dx0, dx1
     const float* tab;       // (B, Hp, 8) effective first-layer weights, slots 0,1 used here
-    float* sgtile;          // [tiles][2][Hp][4] = (G0, G1, S, -)
+    float* sgtile;          // [tiles][Hp][4] = (G0, G1, S, -), both row halves of the tile summed
     float* dfpart;          // [Hp/NB][Mp][2]
     long Mp;
     int N, Timg;
@@ -527,8 +527,12 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                                 pd1[4 * q + r] += vv[r] * w.y;
                             }
                         }
+                        // the two half-waves hold the two row halves of the same feature: one sum per (tile, feature)
+                        g0 += __shfl_xor(g0, 32);
+                        g1 += __shfl_xor(g1, 32);
+                        sv += __shfl_xor(sv, 32);
                         const int k = nb * NB + t * 32 + nl;
-                        *reinterpret_cast<float4*>(a.sgtile + (((tl * 2 + h) * (long)Hp) + k) * 4) = make_float4(g0, g1, sv, 0.0f);
+                        if (h == 0) *reinterpret_cast<float4*>(a.sgtile + (tl * (long)Hp + k) * 4) = make_float4(g0, g1, sv, 0.0f);
                     }
                     // d(coords) of each row: sum this block's NB features = over the tiles (done) and the 32 lanes
                     {
@@ -792,29 +796,45 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dW[n][k] = sum_s slab[s][n][k] (n, k < H), db[n] = sum_s sum_half bslab[s][half][n]
-__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, float* dW, float* db, int H, int Hp, int S) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < (long)H * H) {
-        const int n = idx / H, k = idx % H;
-        // four interleaved chains (fixed order: deterministic), so that several loads are in flight per thread
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+// dW[n][k] = sum_s slab[s][n][k] (n, k < H), db[n] = sum_s sum_half bslab[s][half][n].  The S (typically 64) slabs of
+// 4 Hp^2 bytes sit in L2 / MALL; what bounds this kernel is loads in flight, not bytes.  A block owns 64 consecutive
+// elements of dW; thread = (element, slab group g of 4): it sums slabs g, g+4, g+8, ... in four interleaved chains, and the
+// four groups are combined through LDS in a fixed order (deterministic).  16 independent loads per thread are in flight
+// (r01: one thread per element walked all S slabs, 4 loads in flight: 0.042 ms for 64 MB).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                           float* __restrict__ dW, float* __restrict__ db, int H, int Hp, int S) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + col;
+    const bool in = idx < (long)H * H;
+    float part = 0.0f;
+    if (in) {
+        const int n = (int)(idx / H), k = (int)(idx - (long)n * H);
         const float* p = slab + (long)n * Hp + k;
         const long st = (long)Hp * Hp;
-        int i = 0;
-        for (; i + 3 < S; i += 4) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int i = grp;
+        for (; i + 12 < S; i += 16) {
             s0 += p[(long)i * st];
-            s1 += p[(long)(i + 1) * st];
-            s2 += p[(long)(i + 2) * st];
-            s3 += p[(long)(i + 3) * st];
+            s1 += p[(long)(i + 4) * st];
+            s2 += p[(long)(i + 8) * st];
+            s3 += p[(long)(i + 12) * st];
         }
-        for (; i < S; ++i) s0 += p[(long)i * st];
-        if (dW) dW[idx] = (s0 + s1) + (s2 + s3);
+        for (; i < S; i += 4) s0 += p[(long)i * st];
+        part = (s0 + s1) + (s2 + s3);
     }
-    if (idx < H && db) {
+    red[grp][col] = part;
+    __syncthreads();
+    if (grp == 0 && in && dW) dW[idx] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (db && blockIdx.x * 64 < H) {  // the first ceil(H / 64) blocks also carry 64 bias entries each
+        __syncthreads();
+        const int n = blockIdx.x * 64 + col;
         float s = 0.0f;
-        for (int i = 0; i < 2 * S; ++i) s += bslab[(long)i * Hp + idx];
-        db[idx] = s;
+        if (n < H)
+            for (int i = grp; i < 2 * S; i += 4) s += bslab[(long)i * Hp + n];
+        red[grp][col] = s;
+        __syncthreads();
+        if (grp == 0 && n < H) db[n] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
     }
 }
 

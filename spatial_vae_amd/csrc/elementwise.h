@@ -66,51 +66,61 @@ struct RowGeo {
 };
 
 // ---------------------------------------------------------------- coordinate layer, forward
-// a0[m][k] = act( sum_p feat_p(x''_m) tab[b][k][p] + tab[b][k][5] ): thread = (octet, k, half)
-// computes four consecutive rows and stores them as one 16-byte vector; the thread index IS the
-// output offset, so the 411 MB stream (BASELINE cfg 2) is written perfectly linearly.
-constexpr int kL0Group = 4;  // row octets of one image per thread: the table entry is loaded once for all of them
+// a0[m][k] = act( sum_p feat_p(x''_m) tab[b][k][p] + tab[b][k][5] ).  A block owns 128 features x 2 row-halves
+// (thread = (k, half)) and a chunk of up to kL0Chunk row octets of ONE image: the posed coordinates of the chunk's rows
+// are computed once per block into LDS ([octet][half] -> x0 x 4 | x1 x 4, read back as two broadcast ds_read_b128: the
+// 32 lanes of a half-wave share an address), the thread's table entry is loaded once, and the loop does nothing but
+// 2 LDS reads, 8 FMAs, 4 activations and ONE 16-byte store per octet (1 KiB contiguous per wave instruction).  r01's
+// form re-read 16 coordinates and the table entry for every 4 stores (19 loads per 4 stores: 4.2 TB/s); this one is
+// bound by the store stream.
+constexpr int kL0Chunk = 32;  // row octets per block (LDS: 32 x 2 x 32 B = 2 KiB)
 template <int ACT>
-__global__ void layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ posebuf, const float* __restrict__ tab,
-                                  float* __restrict__ a0, RowGeo g, long ngroups) {
-    // grid: x covers the Hp*2 (feature, half) pairs of one row octet, (y, z) groups of kL0Group octets of one image
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const long grp = (long)blockIdx.z * gridDim.y + blockIdx.y;
-    if (t >= g.Hp * 2 || grp >= ngroups) return;
-    const int h = t & 1, k = t >> 1;
+__global__ void __launch_bounds__(256) layer0_fwd_kernel(PoseArgs pose, const float4* __restrict__ posebuf,
+                                                         const float* __restrict__ tab, float* __restrict__ a0, RowGeo g,
+                                                         int oct_per_chunk, int chunks_per_image, long nchunks) {
+    __shared__ float4 xs[kL0Chunk * 2 * 2];
+    const long chunk = (long)blockIdx.z * gridDim.y + blockIdx.y;
+    if (chunk >= nchunks) return;  // block-uniform
+    const int b = (int)(chunk / chunks_per_image), ci = (int)(chunk - (long)b * chunks_per_image);
     const int oimg = g.Npad >> 3;
-    const int gpi = (oimg + kL0Group - 1) / kL0Group;
-    const int b = (int)(grp / gpi);
-    const int o0 = (int)(grp - (long)b * gpi) * kL0Group;
+    const int oc0 = ci * oct_per_chunk;
+    const int noc = (oc0 + oct_per_chunk <= oimg) ? oct_per_chunk : oimg - oc0;
     const float4 pb = posebuf[b];  // identity (1, 0, 0, 0) when the coordinates are explicit
+    const float* cbase = pose.coords ? pose.coords + (long)b * g.N * 2 : pose.grid;
+    float* xf = reinterpret_cast<float*>(xs);
+    for (int j = threadIdx.x; j < noc * 8; j += 256) {  // row j of the chunk; pad rows (i >= N) are (0, 0)
+        const int i = oc0 * 8 + j;
+        float x0 = 0.0f, x1 = 0.0f;
+        if (i < g.N) {
+            const float2 raw = *reinterpret_cast<const float2*>(cbase + (long)i * 2);
+            x0 = pb.x * raw.x - pb.y * raw.y + pb.z;
+            x1 = pb.y * raw.x + pb.x * raw.y + pb.w;
+        }
+        const int slot = (j >> 2) * 8 + (j & 3);  // (octet, half) pair j >> 2: [x0 x 4][x1 x 4]
+        xf[slot] = x0;
+        xf[slot + 4] = x1;
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.Hp * 2) return;
+    const int h = t & 1, k = t >> 1;
     const float4* tp = reinterpret_cast<const float4*>(tab + ((long)b * g.Hp + k) * kSlots);
     const float4 t0 = tp[0], t1 = tp[1];
-    // the rows' coordinates: independent loads, no branches (pad rows re-read row N-1 and are zeroed)
-    const float* cbase = pose.coords ? pose.coords + (long)b * g.N * 2 : pose.grid;
-    float2 raw[kL0Group][4];
-#pragma unroll
-    for (int j = 0; j < kL0Group; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = ((o0 + j) << 3) + 4 * h + e;
-            raw[j][e] = *reinterpret_cast<const float2*>(cbase + (long)(i < g.N ? i : g.N - 1) * 2);
-        }
-#pragma unroll
-    for (int j = 0; j < kL0Group; ++j) {
-        if (o0 + j >= oimg) break;
+    const long ostride = (long)g.Hp * 8;
+    float* dst = a0 + (((long)b * oimg + oc0) * g.Hp * 2 + t) * 4;
+    const bool expand = g.in_dim == 5;
+#pragma unroll 4
+    for (int jo = 0; jo < noc; ++jo) {
+        const float4 X0 = xs[(jo * 2 + h) * 2], X1 = xs[(jo * 2 + h) * 2 + 1];
+        const float x0[4] = {X0.x, X0.y, X0.z, X0.w}, x1[4] = {X1.x, X1.y, X1.z, X1.w};
         float out[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool in = ((o0 + j) << 3) + 4 * h + e < g.N;
-            float2 x;
-            x.x = in ? pb.x * raw[j][e].x - pb.y * raw[j][e].y + pb.z : 0.0f;
-            x.y = in ? pb.y * raw[j][e].x + pb.x * raw[j][e].y + pb.w : 0.0f;
-            float v = t1.y + x.x * t0.x + x.y * t0.y;
-            if (g.in_dim == 5) v += (x.x * x.x) * t0.z + (x.y * x.y) * t0.w + (x.x * x.y) * t1.x;
+            float v = t1.y + x0[e] * t0.x + x1[e] * t0.y;
+            if (expand) v += (x0[e] * x0[e]) * t0.z + (x1[e] * x1[e]) * t0.w + (x0[e] * x1[e]) * t1.x;
             out[e] = act_fwd<ACT>(v);
         }
-        const long o = (long)b * oimg + o0 + j;
-        *reinterpret_cast<float4*>(a0 + (o * g.Hp * 2 + t) * 4) = make_float4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<float4*>(dst + jo * ostride) = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -184,24 +194,28 @@ __global__ void logits_finish_kernel(const float* __restrict__ lpart, const floa
 }
 
 // ---------------------------------------------------------------- output layer, backward, step 1
-// do_p[c][mp] = dy * dy_scale[b] * (softplus') * s(1-s) on valid rows (pad rows stay 0 from the
-// memset), recomputing s from the logits exactly as the forward did.
+// do_p[c][mp] = dy * dy_scale[b] * (softplus') * s(1-s), recomputing s from the logits exactly as the forward did.  The
+// grid runs over the PADDED row space (c, mp) and writes the exact zeros of the pad rows itself (no memset launch).
 __global__ void dlogits_kernel(const float* __restrict__ logits, const float* __restrict__ dy,
                                const float* __restrict__ dy_scale, float* __restrict__ do_p, int B, int N, int Npad,
                                int C, int softplus, long Mp, unsigned* __restrict__ amax) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over C * Mp
     float m = 0.0f;
-    if (idx < (long)B * N * C) {
-        const int c = idx % C;
-        const long bi = idx / C;
-        const int i = bi % N, b = bi / N;
-        const float lg = logits[idx];
-        const float s = 1.0f / (1.0f + expf(-lg));
-        float g = dy[idx];
-        if (dy_scale) g *= dy_scale[b];
-        if (softplus && c == 0) g *= 1.0f / (1.0f + expf(-s));
-        const float v = g * s * (1.0f - s);
-        do_p[(long)c * Mp + (long)b * Npad + i] = v;
+    if (idx < (long)C * Mp) {
+        const int c = (int)(idx / Mp);
+        const long mp = idx - (long)c * Mp;
+        const int b = (int)(mp / Npad), i = (int)(mp - (long)b * Npad);
+        float v = 0.0f;
+        if (i < N) {
+            const long src = ((long)b * N + i) * C + c;
+            const float lg = logits[src];
+            const float s = 1.0f / (1.0f + expf(-lg));
+            float g = dy[src];
+            if (dy_scale) g *= dy_scale[b];
+            if (softplus && c == 0) g *= 1.0f / (1.0f + expf(-s));
+            v = g * s * (1.0f - s);
+        }
+        do_p[idx] = v;
         m = fabsf(v);
     }
     if (amax) {  // fp16x3 mode: max |do| (non-negative floats order like their bit patterns; max is order-independent)
@@ -389,36 +403,79 @@ __global__ void layer0_bwd_coords_kernel(PoseArgs pose, const float4* __restrict
     }
 }
 
-// (a') fused path: the data-gradient GEMM of the first hidden layer already reduced dh0 over each 32-row tile
-//      (dense_kernel<.., FIRST>): sgtile[tile][half][k] = (G0, G1, S, -).  Sum the tiles and halves of each image.
-__global__ void sgtile_reduce_kernel(const float* __restrict__ sgtile, float* __restrict__ sgimg, int B, int Hp, int Timg) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*Hp
-    if (idx >= (long)B * Hp) return;
-    const int k = idx % Hp, b = idx / Hp;
-    float g0 = 0.0f, g1 = 0.0f, sv = 0.0f;
-    for (int t = 0; t < Timg; ++t)
-        for (int h = 0; h < 2; ++h) {
-            const float4 v = *reinterpret_cast<const float4*>(sgtile + ((((long)b * Timg + t) * 2 + h) * Hp + k) * 4);
-            g0 += v.x; g1 += v.y; sv += v.z;
+// (a') + (b') + (d) + (e), fused path: the data-gradient GEMM of the first hidden layer already reduced dh0 over each
+//      32-row tile (dense_kernel<.., FIRST>: sgtile[tile][k] = (G0, G1, S, -), both row halves summed; the fp16x3 kernel
+//      keeps the halves apart: nhalf = 2) and over each column block (dfpart[block][mp] = d(coords) partial).  What is left
+//      are per-image, fixed-order sums, done by ONE launch of B x 2 blocks instead of four kernels:
+//        role 0 (blockIdx.y == 0): sgimg[b][k] = sum over the image's tiles (and halves); then dz[b][q] from it (d);
+//        role 1 (blockIdx.y == 1): d(coords)[b][i] = sum over column blocks; then dtheta[b], ddx[b] from it (e).
+__global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __restrict__ sgtile, int nhalf, int Timg, int H, int Hp,
+                                                                float* __restrict__ sgimg, const float* __restrict__ latent_w,
+                                                                const float* __restrict__ bil_w, float* __restrict__ dz, int Zd,
+                                                                int in_dim, const float* __restrict__ dfpart, int nblocks, int N,
+                                                                int Npad, long Mp, float* __restrict__ dcoords,
+                                                                const float* __restrict__ grid, const float4* __restrict__ posebuf,
+                                                                float* __restrict__ dtheta, float* __restrict__ ddx) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    if (blockIdx.y == 0) {
+        for (int k = threadIdx.x; k < Hp; k += 256) {
+            float g0 = 0.0f, g1 = 0.0f, sv = 0.0f;
+            for (int t = 0; t < Timg; ++t)
+                for (int h = 0; h < nhalf; ++h) {
+                    const float4 v = *reinterpret_cast<const float4*>(sgtile + ((((long)b * Timg + t) * nhalf + h) * Hp + k) * 4);
+                    g0 += v.x; g1 += v.y; sv += v.z;
+                }
+            float4* dst = reinterpret_cast<float4*>(sgimg + ((long)b * Hp + k) * kSlots);
+            dst[0] = make_float4(g0, g1, 0.0f, 0.0f);
+            dst[1] = make_float4(0.0f, sv, 0.0f, 0.0f);
         }
-    float4* dst = reinterpret_cast<float4*>(sgimg + idx * kSlots);
-    dst[0] = make_float4(g0, g1, 0.0f, 0.0f);
-    dst[1] = make_float4(0.0f, sv, 0.0f, 0.0f);
-}
-
-// (b') fused path: d(coords)[b][i] = sum over column blocks of dfpart[block][mp] (in_dim == 2: dfeat = dcoords)
-__global__ void coords_finish_kernel(const float* __restrict__ dfpart, float* __restrict__ dcoords, int nblocks, int B,
-                                     int N, int Npad, long Mp) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // over B*N
-    if (idx >= (long)B * N) return;
-    const int i = idx % N, b = idx / N;
-    const long mp = (long)b * Npad + i;
-    float d0 = 0.0f, d1 = 0.0f;
-    for (int nb = 0; nb < nblocks; ++nb) {
-        const float2 v = *reinterpret_cast<const float2*>(dfpart + ((long)nb * Mp + mp) * 2);
-        d0 += v.x; d1 += v.y;
+        if (!dz || Zd <= 0) return;
+        // dz[b][q] = sum_k S_b[k] W_z[k][q] + sum_{k,p} G_b[k][p] W_bi[k][p][q]; every thread re-reads what it wrote itself
+        for (int q = 0; q < Zd; ++q) {
+            float s = 0.0f;
+            for (int k = threadIdx.x; k < H; k += 256) {
+                const float* e = sgimg + ((long)b * Hp + k) * kSlots;
+                s += e[kBiasSlot] * latent_w[(long)k * Zd + q];
+                if (bil_w)
+                    for (int p = 0; p < in_dim; ++p) s += e[p] * bil_w[((long)k * in_dim + p) * Zd + q];
+            }
+            s = block_sum256(s, red);
+            if (threadIdx.x == 0) dz[(long)b * Zd + q] = s;
+        }
+        return;
     }
-    *reinterpret_cast<float2*>(dcoords + idx * 2) = make_float2(d0, d1);
+    if (!dcoords) return;
+    const bool want_pose = dtheta || ddx;
+    float4 pb = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if (want_pose) pb = posebuf[b];
+    float st = 0.0f, s0 = 0.0f, s1 = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const long mp = (long)b * Npad + i;
+        float d0 = 0.0f, d1 = 0.0f;
+        for (int nb = 0; nb < nblocks; ++nb) {
+            const float2 v = *reinterpret_cast<const float2*>(dfpart + ((long)nb * Mp + mp) * 2);
+            d0 += v.x; d1 += v.y;
+        }
+        *reinterpret_cast<float2*>(dcoords + ((long)b * N + i) * 2) = make_float2(d0, d1);
+        if (want_pose) {  // dtheta[b] = sum_i dx0 (-s g0 - c g1) + dx1 (c g0 - s g1);  ddx[b] = sum_i dcoords[b,i]
+            const float2 gr = *reinterpret_cast<const float2*>(grid + (long)i * 2);
+            st += d0 * (-pb.y * gr.x - pb.x * gr.y) + d1 * (pb.x * gr.x - pb.y * gr.y);
+            s0 += d0;
+            s1 += d1;
+        }
+    }
+    if (!want_pose) return;
+    st = block_sum256(st, red);
+    s0 = block_sum256(s0, red);
+    s1 = block_sum256(s1, red);
+    if (threadIdx.x == 0) {
+        if (dtheta) dtheta[b] = st;
+        if (ddx) {
+            ddx[2 * b] = s0;
+            ddx[2 * b + 1] = s1;
+        }
+    }
 }
 
 // (c) first-layer parameter gradients from the per-image sums.  A block owns 32 consecutive (k, slot)
@@ -982,9 +1039,10 @@ __global__ void __launch_bounds__(256) ctf_filter_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------- Adam over a flat buffer (A7: optim.step())
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float step_size, float sqrt_bc2, float b1, float b2, float eps) {
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float step_size, float sqrt_bc2, float b1, float b2, float eps, int zero_grad) {
     // operation order of ATen's Adam: denom = sqrt(v) / sqrt(bc2) + eps;  p += (-step_size) * (m / denom)
+    // zero_grad: the gradient is cleared behind the update (optim.zero_grad(), train_mnist.py:150) -- no separate pass
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         const float4 g4 = *reinterpret_cast<const float4*>(g + i);
@@ -1000,6 +1058,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         *reinterpret_cast<float4*>(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
         *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     } else {
         for (long j = i; j < n; ++j) {
             const float gj = g[j];
@@ -1007,6 +1066,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
             m[j] = mj;
             v[j] = vj;
             p[j] += -step_size * (mj / (sqrtf(vj) / sqrt_bc2 + eps));
+            if (zero_grad) g[j] = 0.0f;
         }
     }
 }

@@ -137,8 +137,11 @@ class FlatGrads(object):
                 p.grad = view
             off += p.numel()
 
-    def zero(self):
-        self.flat.zero_()
+    def zero(self, already_cleared=False):
+        """optim.zero_grad(): clear the flat buffer (unless the optimiser kernel already did) and detach the sink
+        parameters' .grad (the decoder kernels write their views directly)."""
+        if not already_cleared:
+            self.flat.zero_()
         for p in self._sink_list:
             p.grad = None
 
@@ -213,7 +216,7 @@ class TrainStep(object):
         self.master.grad = self.grads.flat
         if on_gpu and fused_adam is None:
             from .ops import FlatAdam    # torch.optim.Adam's arithmetic in one small kernel over the flat buffer
-            self.optim = FlatAdam([self.master], lr=lr)
+            self.optim = FlatAdam([self.master], lr=lr, zero_grad=True)   # the update clears the flat gradient behind itself
         else:
             kw = {"fused": True, "capturable": True} if (fused_adam and on_gpu) else {}
             self.optim = torch.optim.Adam([self.master], lr=lr, **kw)
@@ -293,7 +296,7 @@ class TrainStep(object):
             self.grads.tail.zero_()
         self._reduce()
         self.optim.step()
-        self.grads.zero()
+        self.grads.zero(already_cleared=getattr(self.optim, "zero_grad_in_step", False))
         return out
 
     def __call__(self, x, *batch, weight=1.0, **kw):

@@ -421,8 +421,11 @@ class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam's update (amsgrad off, no weight decay) for ONE flat fp32 CUDA parameter, executed by
     svae_adam_step.  Same defaults and state names (step, exp_avg, exp_avg_sq) as torch.optim.Adam."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, zero_grad=False):
+        """zero_grad=True: step() also clears each parameter's .grad buffer in the same kernel (the loop's
+        optim.zero_grad(), train_mnist.py:150, without a second pass)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.zero_grad_in_step = bool(zero_grad)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -444,4 +447,4 @@ class FlatAdam(torch.optim.Optimizer):
                 with torch.cuda.device(p.device):
                     _lib.check(L.svae_adam_step(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
                                                 st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"], b1, b2, group["eps"],
-                                                st["step"], _stream(p.device)))
+                                                st["step"], 1 if self.zero_grad_in_step else 0, _stream(p.device)))

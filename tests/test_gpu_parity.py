@@ -133,6 +133,16 @@ def test_flat_adam_matches_torch_adam():
     # implementations order the divisions differently
     assert (np.abs(an - bn) <= 4 * np.spacing(np.maximum(np.abs(bn), np.float32(5e-3)))).all()
     assert np.abs(an - w0.cpu().numpy()).max() > 1e-3          # and the parameters did move
+    assert a.grad.abs().max().item() > 0                        # the plain form leaves the gradient alone
+    # zero_grad=True: the same update, and the gradient buffer is cleared in the same kernel (vector body and scalar tail)
+    c = torch.nn.Parameter(w0.clone())
+    d = torch.nn.Parameter(w0.clone())
+    oc, od = FlatAdam([c], lr=1e-3, zero_grad=True), FlatAdam([d], lr=1e-3)
+    g = torch.randn_like(w0)
+    c.grad, d.grad = g.clone(), g.clone()
+    oc.step()
+    od.step()
+    assert torch.equal(c.detach(), d.detach()) and float(c.grad.abs().max()) == 0.0
 
 
 def test_train_step_updates_match_plain_torch_adam():
