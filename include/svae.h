@@ -133,6 +133,18 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
                          svae_stream_t stream);
 
 /*
+ * The same forward with the per-pixel Bernoulli log-likelihood folded into the output layer's last kernel: replaces
+ * SpatialGenerator.forward AND  -F.binary_cross_entropy(y_hat, y) * size  (train_mnist.py:77-81; train_galaxy.py:115-119) in
+ * per-image form, with torch's clamps (see svae_bce_loglik) taken on the same fp32 sigmoid value.  No second pass over y.
+ *   target (B, N, C); loglik (B); dll_dy (B, N, C) = d(loglik_b)/d(y), may be NULL for inference.
+ * Backward: hand dll_dy to svae_decoder_backward as `dy` and the upstream gradient of loglik as `dy_scale`.
+ * Refused with SVAE_FLAG_SOFTPLUS (the reference's binary_cross_entropy raises on values above 1).
+ */
+int svae_decoder_forward_bce(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z,
+                             const float* target, float* y, float* logits, float* loglik, float* dll_dy, void* saved, void* ws,
+                             size_t ws_bytes, svae_stream_t stream);
+
+/*
  * Decoder backward: replaces the autograd replay of the lines above.
  *   logits    (B, N, C) the forward's pre-Sigmoid output (the wrapper keeps it, as autograd
  *             keeps the Sigmoid's result in the reference)

@@ -76,6 +76,9 @@ def lib():
     L.svae_decoder_forward.restype = ctypes.c_int
     L.svae_decoder_forward.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Params), ctypes.POINTER(Pose), vp,
                                        vp, vp, vp, vp, sz, vp]
+    L.svae_decoder_forward_bce.restype = ctypes.c_int
+    L.svae_decoder_forward_bce.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Params), ctypes.POINTER(Pose), vp,
+                                           vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.svae_decoder_backward.restype = ctypes.c_int
     L.svae_decoder_backward.argtypes = [ctypes.POINTER(Desc), ctypes.POINTER(Params), ctypes.POINTER(Pose), vp,
                                         vp, vp, vp, vp, ctypes.POINTER(Params), vp, ctypes.POINTER(PoseGrads),

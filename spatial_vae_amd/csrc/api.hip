@@ -642,11 +642,20 @@ size_t svae_workspace_bytes(const svae_desc* d) {
     return make_plan(make_geo(*d), nullptr, nullptr).ws_bytes;
 }
 
-int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z, float* y,
-                         float* logits, void* saved, void* ws, size_t ws_bytes, svae_stream_t stream) {
+}  // extern "C"
+
+namespace {
+// svae_decoder_forward, optionally with the Bernoulli log-likelihood folded into the output layer (bce_target != NULL)
+int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z, float* y,
+                         float* logits, void* saved, void* ws, size_t ws_bytes, svae_stream_t stream, const float* bce_target,
+                         float* loglik, float* dll_dy) {
     int rc;
     if ((rc = check_desc(d)) || (rc = check_params(d, p)) || (rc = check_pose(pose))) return rc;
     if (!y) return fail(SVAE_E_INVALID, "y is null");
+    if (bce_target && !loglik) return fail(SVAE_E_INVALID, "a Bernoulli target needs the loglik output");
+    if (bce_target && (d->flags & SVAE_FLAG_SOFTPLUS))
+        return fail(SVAE_E_INVALID, "softplus output with a Bernoulli likelihood: the reference's binary_cross_entropy rejects "
+                                    "values above 1 (train_mnist.py:81)");
     if (d->Zd > 0 && !z) return fail(SVAE_E_INVALID, "latent_dim > 0 but z is null");
     if (saved && (reinterpret_cast<uintptr_t>(saved) & 255)) return fail(SVAE_E_WORKSPACE, "saved not 256-byte aligned");
     const Geo g = make_geo(*d);
@@ -704,10 +713,13 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
     }
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
-        hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
-                           logits, row_geo(g), g.C, g.ntile / (split ? split_nt_fwd(g) : dense_nt_first(g.ntile)),
-                           (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0,
-                           (long)g.Mp);
+        const int nblk = g.ntile / (split ? split_nt_fwd(g) : dense_nt_first(g.ntile));
+        if (bce_target)
+            hipLaunchKernelGGL(logits_finish_bce_kernel, dim3(g.B), dim3(256), 0, st, pl.dfpart, p->out_b, bce_target, y, logits,
+                               loglik, dll_dy, row_geo(g), g.C, nblk, (long)g.Mp);
+        else
+            hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
+                               logits, row_geo(g), g.C, nblk, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
         return launch_status("svae_decoder_forward");
     }
     switch (g.C) {
@@ -716,7 +728,26 @@ int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_po
         case 3: launch_out_fwd<3>(g, pl.act[g.L - 1], p, y, logits, st); break;
         default: launch_out_fwd<4>(g, pl.act[g.L - 1], p, y, logits, st); break;
     }
+    if (bce_target) {  // no fused finish for this geometry (C > 2 or no hidden GEMM): the plain per-image pass over y
+        Scope prof(K_BCE, st);
+        hipLaunchKernelGGL(bce_kernel, dim3(g.B), dim3(256), 0, st, y, bce_target, loglik, dll_dy, g.N * g.C);
+    }
     return launch_status("svae_decoder_forward");
+}
+}  // namespace
+
+extern "C" {
+
+int svae_decoder_forward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z, float* y,
+                         float* logits, void* saved, void* ws, size_t ws_bytes, svae_stream_t stream) {
+    return decoder_forward_impl(d, p, pose, z, y, logits, saved, ws, ws_bytes, stream, nullptr, nullptr, nullptr);
+}
+
+int svae_decoder_forward_bce(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z,
+                             const float* target, float* y, float* logits, float* loglik, float* dll_dy, void* saved, void* ws,
+                             size_t ws_bytes, svae_stream_t stream) {
+    if (!target) return fail(SVAE_E_INVALID, "svae_decoder_forward_bce: target is null");
+    return decoder_forward_impl(d, p, pose, z, y, logits, saved, ws, ws_bytes, stream, target, loglik, dll_dy);
 }
 
 int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_pose* pose, const float* z,
@@ -769,7 +800,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                                   : launch_out_bwd_split_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, dh32, st);
         ob_nparts = nparts;
         Scope prof(K_SMALL_BWD, st);
-        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, st, pl.wpart, pl.bpart,
                            grads->out_w, grads->out_b, g.C, g.H, g.Hp, nparts);
     } else if (!fused_out) {
         const float* alast = pl.act[g.L - 1];
@@ -780,7 +811,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             default: launch_out_bwd_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, pl.dh[cur], st); break;
         }
         Scope prof(K_SMALL_BWD, st);
-        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, st, pl.wpart, pl.bpart,
                            grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2);
     }
 
@@ -821,7 +852,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                 hipLaunchKernelGGL(colsum_reduce_kernel, dim3(g.Hp / 32), dim3(256), 0, st, pl.hbpart, grads->hidden_b[l - 1],
                                    g.H, g.Hp, ob_nparts);
             if (last)
-                hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * (g.Hp / 32) + 1), dim3(256), 0, st, pl.wpart, pl.bpart,
+                hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, st, pl.wpart, pl.bpart,
                                    grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.wg_S * 2);
         }
         DenseArgs a;
@@ -878,7 +909,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                    dc, row_geo(g), g.noct);
             }
         }
-        hipLaunchKernelGGL(layer0_param_grads_kernel, dim3((unsigned)(((long)g.H * kSlots + 31) / 32)), dim3(256), 0, st,
+        hipLaunchKernelGGL(layer0_param_grads_kernel, dim3((unsigned)(((long)g.H * kSlots + kPgCols - 1) / kPgCols)), dim3(256), 0, st,
                            pl.sgimg, z, grads->coord_w, grads->coord_b, g.Zd > 0 ? grads->latent_w : nullptr,
                            bil ? grads->bilinear_w : nullptr, g.B, g.H, g.Hp, g.Zd, g.in_dim);
         if (!fused_first) {

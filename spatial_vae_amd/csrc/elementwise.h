@@ -193,6 +193,38 @@ __global__ void logits_finish_kernel(const float* __restrict__ lpart, const floa
     }
 }
 
+// The same finish with the Bernoulli log-likelihood of train_mnist.py:78-81 / train_galaxy.py:116-119 folded in (A5 inside
+// A4's last kernel): one block per image sums the partial logits, applies bias + Sigmoid, writes y (and the logits) and, from
+// the SAME fp32 sigmoid value torch would see, the clamped log terms of F.binary_cross_entropy -- loglik[b] --
+// and d(loglik_b)/d(y) -- dll -- exactly as bce_kernel computes them from y in a second pass.
+__global__ void __launch_bounds__(256) logits_finish_bce_kernel(const float* __restrict__ lpart, const float* __restrict__ out_b,
+                                                                const float* __restrict__ target, float* __restrict__ y,
+                                                                float* __restrict__ logits, float* __restrict__ loglik,
+                                                                float* __restrict__ dll, RowGeo g, int C, int nblk, long Mp) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < g.N; i += 256) {
+        const long m = (long)b * g.Npad + i;
+        const long t = (long)b * g.N + i;
+        for (int c = 0; c < C; ++c) {
+            float lg = 0.0f;
+            for (int k = 0; k < nblk; ++k) lg += lpart[((long)k * C + c) * Mp + m];
+            lg += out_b[c];
+            const float s = 1.0f / (1.0f + expf(-lg));
+            const float tg = target[t * C + c];
+            y[t * C + c] = s;
+            if (logits) logits[t * C + c] = lg;
+            const float ls = fmaxf(logf(s), -100.0f);
+            const float l1s = fmaxf(log1pf(-s), -100.0f);
+            acc += tg * ls + (1.0f - tg) * l1s;
+            if (dll) dll[t * C + c] = -(s - tg) / fmaxf((1.0f - s) * s, 1e-12f);
+        }
+    }
+    acc = block_sum256(acc, red);
+    if (threadIdx.x == 0) loglik[b] = acc;
+}
+
 // ---------------------------------------------------------------- output layer, backward, step 1
 // do_p[c][mp] = dy * dy_scale[b] * (softplus') * s(1-s), recomputing s from the logits exactly as the forward did.  The
 // grid runs over the PADDED row space (c, mp) and writes the exact zeros of the pad rows itself (no memset launch).
@@ -273,34 +305,52 @@ __global__ void out_bwd_kernel(const float* __restrict__ a, const float* __restr
     }
 }
 
-// dW_o[c][n] = sum over (chunk, half) of wpart; db_o[c] = sum over (chunk, half) of bpart.  The order is
-// fixed (8 interleaved partial sums per column, combined in LDS in a fixed order).  A block owns 32
-// consecutive columns of one channel: thread = (column, part lane), so every sweep over the partials is a
-// coalesced 128-byte read and 8 independent chains run per column.
-__global__ void out_bwd_reduce_kernel(const float* __restrict__ wpart, const float* __restrict__ bpart,
-                                      float* __restrict__ dWo, float* __restrict__ dbo, int C, int H, int Hp,
-                                      int nparts) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int blocks_per_c = Hp / 32;
-    if (blockIdx.x == (unsigned)(C * blocks_per_c)) {  // last block: the C bias gradients
-        if (threadIdx.x < C && dbo) {
-            float s = 0.0f;
-            for (int i = 0; i < nparts; ++i) s += bpart[(long)i * C + threadIdx.x];
-            dbo[threadIdx.x] = s;
+// dW_o[c][n] = sum over (chunk, half) of wpart; db_o[c] = sum over (chunk, half) of bpart, in a fixed order.  The
+// partials are ~1 MB in L2; the kernel is bound by round trips, so it is built for loads in flight: a block of 1024 threads
+// owns 64 consecutive columns of one channel (a 256-byte coalesced sweep per part), thread = (column, part lane of 16), each
+// thread sums its parts in 8 interleaved chains, and the 16 lanes of a column are combined through LDS in a fixed order
+// (r01: 32 columns x 8 lanes with one chain per thread -- 64 dependent loads -- took 33 us for 512 parts).
+constexpr int kObrLanes = 16;
+__global__ void __launch_bounds__(1024) out_bwd_reduce_kernel(const float* __restrict__ wpart, const float* __restrict__ bpart,
+                                                              float* __restrict__ dWo, float* __restrict__ dbo, int C, int H,
+                                                              int Hp, int nparts) {
+    __shared__ float red[kObrLanes][65];
+    const int col = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int blocks_per_c = (Hp + 63) / 64;
+    if (blockIdx.x == (unsigned)(C * blocks_per_c)) {  // last block: the C bias gradients, same lane scheme over bpart
+        float s = 0.0f;
+        if (col < C)
+            for (int i = pl; i < nparts; i += kObrLanes) s += bpart[(long)i * C + col];
+        red[pl][col] = s;
+        __syncthreads();
+        if (pl == 0 && col < C && dbo) {
+            float t = red[0][col];
+#pragma unroll
+            for (int j = 1; j < kObrLanes; ++j) t += red[j][col];
+            dbo[col] = t;
         }
         return;
     }
-    const int c = blockIdx.x / blocks_per_c, n = (blockIdx.x % blocks_per_c) * 32 + col;
+    const int c = blockIdx.x / blocks_per_c, n = (blockIdx.x % blocks_per_c) * 64 + col;
     float s = 0.0f;
-#pragma unroll 4
-    for (int i = pl; i < nparts; i += 8) s += wpart[((long)i * C + c) * Hp + n];
+    if (n < Hp) {
+        const float* p = wpart + (long)c * Hp + n;
+        const long st = (long)C * Hp;
+        float ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = pl;
+        for (; i + 7 * kObrLanes < nparts; i += 8 * kObrLanes) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ch[j] += p[(long)(i + j * kObrLanes) * st];
+        }
+        for (; i < nparts; i += kObrLanes) ch[0] += p[(long)i * st];
+        s = ((ch[0] + ch[1]) + (ch[2] + ch[3])) + ((ch[4] + ch[5]) + (ch[6] + ch[7]));
+    }
     red[pl][col] = s;
     __syncthreads();
     if (pl == 0 && n < H && dWo) {
         float t = red[0][col];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) t += red[j][col];
+        for (int j = 1; j < kObrLanes; ++j) t += red[j][col];
         dWo[(long)c * H + n] = t;
     }
 }
@@ -420,12 +470,26 @@ __global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __r
     const int b = blockIdx.x;
     if (blockIdx.y == 0) {
         for (int k = threadIdx.x; k < Hp; k += 256) {
-            float g0 = 0.0f, g1 = 0.0f, sv = 0.0f;
-            for (int t = 0; t < Timg; ++t)
-                for (int h = 0; h < nhalf; ++h) {
-                    const float4 v = *reinterpret_cast<const float4*>(sgtile + ((((long)b * Timg + t) * nhalf + h) * Hp + k) * 4);
-                    g0 += v.x; g1 += v.y; sv += v.z;
+            // the image's Timg * nhalf partial rows, 8 loads in flight (fixed order: chain j takes rows j, j+8, ...)
+            const float* src = sgtile + ((long)b * Timg * nhalf * Hp + k) * 4;
+            const long rst = (long)Hp * 4;
+            const int rows = Timg * nhalf;
+            float c0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int r = 0;
+            for (; r + 7 < rows; r += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + (r + j) * rst);
+                    c0[j] += v.x; c1[j] += v.y; c2[j] += v.z;
                 }
+            }
+            for (int j = 0; r < rows; ++r, ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(src + r * rst);
+                c0[j] += v.x; c1[j] += v.y; c2[j] += v.z;
+            }
+            const float g0 = ((c0[0] + c0[1]) + (c0[2] + c0[3])) + ((c0[4] + c0[5]) + (c0[6] + c0[7]));
+            const float g1 = ((c1[0] + c1[1]) + (c1[2] + c1[3])) + ((c1[4] + c1[5]) + (c1[6] + c1[7]));
+            const float sv = ((c2[0] + c2[1]) + (c2[2] + c2[3])) + ((c2[4] + c2[5]) + (c2[6] + c2[7]));
             float4* dst = reinterpret_cast<float4*>(sgimg + ((long)b * Hp + k) * kSlots);
             dst[0] = make_float4(g0, g1, 0.0f, 0.0f);
             dst[1] = make_float4(0.0f, sv, 0.0f, 0.0f);
@@ -478,56 +542,88 @@ __global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __r
     }
 }
 
-// (c) first-layer parameter gradients from the per-image sums.  A block owns 32 consecutive (k, slot)
-//     columns of sgimg; thread = (column, image lane): 8 interleaved partial sums over the images per
-//     column (coalesced 128-byte sweeps), combined in LDS in a fixed order.
+// (c) first-layer parameter gradients from the per-image sums.  A block owns 16 consecutive (k, slot) columns of sgimg;
+//     thread = (column, image lane of 16): each lane walks its images ONCE (4 loads in flight), accumulating the plain sum
+//     and the z-weighted sums of one chunk of latent dimensions together; the 16 lanes are combined in LDS in a fixed order.
 //     dW_c[k][p] = sum_b G_b[k][p];  db_c[k] = sum_b S_b[k];  dW_z[k][q] = sum_b S_b[k] z[b][q];
 //     dW_bi[k][p][q] = sum_b G_b[k][p] z[b][q]
 constexpr int kZChunk = 8;
-__global__ void layer0_param_grads_kernel(const float* __restrict__ sgimg, const float* __restrict__ z,
-                                          float* __restrict__ dWc, float* __restrict__ dbc, float* __restrict__ dWz,
-                                          float* __restrict__ dWbi, int B, int H, int Hp, int Zd, int in_dim) {
-    __shared__ float red[8][33];
-    const int col = threadIdx.x & 31, bl = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + col;  // over H * kSlots
+constexpr int kPgCols = 16, kPgLanes = 16;
+__global__ void __launch_bounds__(256) layer0_param_grads_kernel(const float* __restrict__ sgimg, const float* __restrict__ z,
+                                                                 float* __restrict__ dWc, float* __restrict__ dbc,
+                                                                 float* __restrict__ dWz, float* __restrict__ dWbi, int B, int H,
+                                                                 int Hp, int Zd, int in_dim) {
+    __shared__ float red[kPgLanes][kPgCols + 1];
+    const int col = threadIdx.x & (kPgCols - 1), bl = threadIdx.x / kPgCols;
+    const int t = blockIdx.x * kPgCols + col;  // over H * kSlots
     const bool in_range = t < H * kSlots;
     const int k = in_range ? t / kSlots : 0, slot = in_range ? t % kSlots : 0;
     const bool is_g = in_range && slot < in_dim, is_s = in_range && slot == kBiasSlot;
     const float* src = sgimg + (long)k * kSlots + slot;
     const long bstride = (long)Hp * kSlots;
-    auto combine = [&](float v) {  // fixed-order sum of the 8 image lanes of this column; valid where bl == 0
+    auto combine = [&](float v) {  // fixed-order sum of the image lanes of this column; valid where bl == 0
         __syncthreads();
         red[bl][col] = v;
         __syncthreads();
         float r = red[0][col];
 #pragma unroll
-        for (int j = 1; j < 8; ++j) r += red[j][col];
+        for (int j = 1; j < kPgLanes; ++j) r += red[j][col];
         return r;
     };
+    const bool want_z = (is_s && dWz) || (is_g && dWbi);
+    const int nq0 = Zd < kZChunk ? Zd : kZChunk;
     float plain = 0.0f;
-    if (is_g || is_s)
-        for (int b = bl; b < B; b += 8) plain += src[b * bstride];
+    float acc[kZChunk];
+#pragma unroll
+    for (int q = 0; q < kZChunk; ++q) acc[q] = 0.0f;
+    if (is_g || is_s) {
+        int b = bl;
+        for (; b + 3 * kPgLanes < B; b += 4 * kPgLanes) {   // 4 images in flight
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = src[(long)(b + j * kPgLanes) * bstride];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                plain += v[j];
+                if (want_z) {
+#pragma unroll
+                    for (int q = 0; q < kZChunk; ++q)
+                        if (q < nq0) acc[q] += v[j] * z[(long)(b + j * kPgLanes) * Zd + q];
+                }
+            }
+        }
+        for (; b < B; b += kPgLanes) {
+            const float v = src[(long)b * bstride];
+            plain += v;
+            if (want_z) {
+#pragma unroll
+                for (int q = 0; q < kZChunk; ++q)
+                    if (q < nq0) acc[q] += v * z[(long)b * Zd + q];
+            }
+        }
+    }
     plain = combine(plain);
     if (bl == 0) {
         if (is_g && dWc) dWc[k * in_dim + slot] = plain;
         if (is_s && dbc) dbc[k] = plain;
     }
-    const bool want_z = (is_s && dWz) || (is_g && dWbi);
     for (int q0 = 0; q0 < Zd; q0 += kZChunk) {  // uniform trip count: combine() holds barriers
-        float acc[kZChunk];
+        if (q0 > 0) {  // latent dimensions beyond the first chunk: another pass over the images
 #pragma unroll
-        for (int q = 0; q < kZChunk; ++q) acc[q] = 0.0f;
-        if (want_z)
-            for (int b = bl; b < B; b += 8) {
-                const float v = src[b * bstride];
+            for (int q = 0; q < kZChunk; ++q) acc[q] = 0.0f;
+            if (want_z)
+                for (int b = bl; b < B; b += kPgLanes) {
+                    const float v = src[(long)b * bstride];
 #pragma unroll
-                for (int q = 0; q < kZChunk; ++q)
-                    if (q0 + q < Zd) acc[q] += v * z[(long)b * Zd + q0 + q];
-            }
+                    for (int q = 0; q < kZChunk; ++q)
+                        if (q0 + q < Zd) acc[q] += v * z[(long)b * Zd + q0 + q];
+                }
+        }
 #pragma unroll
         for (int q = 0; q < kZChunk; ++q) {
+            if (q0 + q >= Zd) break;  // block-uniform
             const float r = combine(acc[q]);
-            if (bl == 0 && want_z && q0 + q < Zd) {
+            if (bl == 0 && want_z) {
                 if (is_s) dWz[(long)k * Zd + q0 + q] = r;
                 else dWbi[((long)k * in_dim + slot) * Zd + q0 + q] = r;
             }

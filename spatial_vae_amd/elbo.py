@@ -83,14 +83,18 @@ def _core(script, x, y, p_net, q_net, rotate, translate, dx_scale, theta_prior, 
         # invert the random rotation: reconstruct the original with the offset added (train_galaxy.py:84-87)
         theta = theta + torch.from_numpy(offset).float().to(theta.device)
 
+    loglik = None
     if hasattr(p_net, "forward_posed"):
-        y_hat, logits = p_net.forward_posed(x, B, theta=theta, dx=dx, z=zc, return_logits=True)
+        if script == "particles" or getattr(p_net, "softplus", False):
+            y_hat, logits = p_net.forward_posed(x, B, theta=theta, dx=dx, z=zc, return_logits=True)
+        else:   # Bernoulli likelihood: scored inside the decoder call (no second pass over y_hat, no scaling pass backward)
+            y_hat, logits, loglik = p_net.forward_posed(x, B, theta=theta, dx=dx, z=zc, bce_target=y)
     else:                                           # --vanilla baseline: ignores coordinates
         y_hat, logits = p_net(x, zc), None
 
     if script == "particles":
         loglik = ops.gaussian_loglik(y_hat.reshape(B, -1), y.view(B, -1), mask=mask, ctf=ctf)
-    else:
+    elif loglik is None:
         loglik = ops.bce_loglik(y_hat.reshape(B, -1), y.reshape(B, -1))
     elbo, log_p_x_g_z, kl_div = ops.elbo_head(loglik, kl_b)     # the two batch means and their difference, one kernel
     return elbo, log_p_x_g_z, kl_div, y_hat, logits

@@ -103,7 +103,7 @@ class SpatialGenerator(nn.Module):
                 lin.append(m)
         return lin[:-1], lin[-1]
 
-    def _decode(self, B, coords, grid, theta, dx, z):
+    def _decode(self, B, coords, grid, theta, dx, z, bce_target=None):
         hidden_lin, out_lin = self._linears()
         hidden = []
         for m in hidden_lin:
@@ -111,7 +111,8 @@ class SpatialGenerator(nn.Module):
         latent_w = self.latent_linear.weight if self.latent_dim > 0 else None
         bil_w = self.bilinear.weight if hasattr(self, "bilinear") else None
         return ops.decoder(self._spec, B, coords, grid, theta, dx, z, self.coord_linear.weight, self.coord_linear.bias,
-                           latent_w, bil_w, out_lin.weight, out_lin.bias, hidden, sinks=getattr(self, "_grad_sinks", None))
+                           latent_w, bil_w, out_lin.weight, out_lin.bias, hidden, sinks=getattr(self, "_grad_sinks", None),
+                           bce_target=bce_target)
 
     def decoder_parameters(self):
         """{sink name: parameter} in the naming ops.decoder uses for gradient sinks (see dp.FlatGrads)."""
@@ -138,11 +139,16 @@ class SpatialGenerator(nn.Module):
         return y
 
     # -- fused entry used by eval_minibatch -----------------------------------------------------
-    def forward_posed(self, grid, batch_size, theta=None, dx=None, z=None, return_logits=False):
+    def forward_posed(self, grid, batch_size, theta=None, dx=None, z=None, return_logits=False, bce_target=None):
         """Decode on the shared grid (N, 2) rotated by theta (B) and shifted by dx (B, 2), without ever
-        materialising the (B, N, 2) coordinates (replaces x.expand/bmm/+dx of eval_minibatch)."""
-        y, logits = self._decode(batch_size, None, grid.contiguous(), theta, dx, z if self.latent_dim > 0 else None)
-        return (y, logits) if return_logits else y
+        materialising the (B, N, 2) coordinates (replaces x.expand/bmm/+dx of eval_minibatch).  With bce_target
+        (the observed images, (B, N[, C])) the per-image Bernoulli log-likelihood is computed in the same call and
+        returned last: (y, logits, loglik)."""
+        out = self._decode(batch_size, None, grid.contiguous(), theta, dx, z if self.latent_dim > 0 else None,
+                           bce_target=bce_target)
+        if bce_target is not None:
+            return out
+        return out if return_logits else out[0]
 
 
 class VanillaGenerator(nn.Module):

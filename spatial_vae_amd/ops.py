@@ -73,10 +73,17 @@ def _fill_params(struct, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, h
 
 
 class _Decoder(torch.autograd.Function):
-    """y, logits = decoder(coords | grid+theta+dx, z; parameters)   (svae_decoder_forward/backward)."""
+    """y, logits[, loglik] = decoder(coords | grid+theta+dx, z; parameters)   (svae_decoder_forward[_bce] / _backward).
+
+    With `target` (a Bernoulli observation, same shape as y) the per-image log-likelihood of train_mnist.py:78-81 comes out
+    of the same call (svae_decoder_forward_bce): no bce kernel, and the backward pass hands the kept d(loglik)/d(y) plus
+    the upstream gradient of loglik to svae_decoder_backward as (dy, dy_scale) -- no elementwise multiply in between."""
+
+    # positions of the tensor arguments in forward(): spec, B, sinks, target come first
+    _ARG0 = 4
 
     @staticmethod
-    def forward(ctx, spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden):
+    def forward(ctx, spec, B, sinks, target, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden):
         L = _lib.lib()
         ref = coords if coords is not None else grid
         _require_hip(ref, "coordinates")
@@ -106,23 +113,48 @@ class _Decoder(torch.autograd.Function):
             saved = torch.empty(max(L.svae_saved_bytes(ctypes.byref(desc)), 256), dtype=torch.uint8, device=device)
         y = torch.empty((B, N, spec.n_out), dtype=torch.float32, device=device)
         logits = torch.empty_like(y)
+        loglik = dll = None
         with torch.cuda.device(device):
-            _lib.check(L.svae_decoder_forward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
-                                              y.data_ptr(), logits.data_ptr(), _p(saved), ws.data_ptr(), ws.numel(),
-                                              _stream(device)))
+            if target is None:
+                _lib.check(L.svae_decoder_forward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
+                                                  y.data_ptr(), logits.data_ptr(), _p(saved), ws.data_ptr(), ws.numel(),
+                                                  _stream(device)))
+            else:
+                target = _f32(target)
+                _require_hip(target, "target")
+                if target.numel() != y.numel():
+                    raise RuntimeError("target shape %s does not match the decoder output %s" % (tuple(target.shape), tuple(y.shape)))
+                loglik = torch.empty(B, dtype=torch.float32, device=device)
+                dll = torch.empty_like(y) if need_grad else None
+                _lib.check(L.svae_decoder_forward_bce(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
+                                                      target.data_ptr(), y.data_ptr(), logits.data_ptr(), loglik.data_ptr(),
+                                                      _p(dll), _p(saved), ws.data_ptr(), ws.numel(), _stream(device)))
         ctx.spec, ctx.B, ctx.N = spec, B, N
         ctx.sinks = sinks
         ctx.saved_buf = saved
+        ctx.dll = dll
         ctx.tensors = (coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits)
         ctx.mark_non_differentiable(logits)
-        return y, logits
+        ctx.set_materialize_grads(False)      # an unused output (y when only loglik feeds the loss) arrives as None
+        if loglik is None:
+            return y, logits
+        return y, logits, loglik
 
     @staticmethod
-    def backward(ctx, dy, _dlogits):
+    def backward(ctx, dy, _dlogits, g_loglik=None):
         L = _lib.lib()
         spec, B, N = ctx.spec, ctx.B, ctx.N
         coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits = ctx.tensors
         device = logits.device
+        # what reaches the kernels: dy (B, N, C) and an optional per-image factor dy_scale (B)
+        dy_scale = None
+        if ctx.dll is not None and g_loglik is not None:
+            if dy is None:
+                dy, dy_scale = ctx.dll, _f32(g_loglik).reshape(-1)      # the fused loss: d(loglik_b)/dy times its upstream gradient
+            else:
+                dy = _f32(dy) + ctx.dll * g_loglik.reshape(-1, 1, 1)    # y_hat is ALSO used downstream: add the two paths
+        elif dy is None:
+            dy = torch.zeros((B, N, spec.n_out), dtype=torch.float32, device=device)
         dy = _f32(dy)
         desc = make_desc(spec, B, N)
         bil = bool(desc.flags & _lib.FLAG_BILINEAR)
@@ -130,8 +162,8 @@ class _Decoder(torch.autograd.Function):
                               bilinear_w if bil else None, out_w, out_b, hidden)
         pose = _lib.Pose()
         pose.coords, pose.grid, pose.theta, pose.dx = _p(coords), _p(grid), _p(theta), _p(dx)
-        # (spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden)
-        ng = ctx.needs_input_grad
+        # (spec, B, sinks, target, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, *hidden)
+        ng = ctx.needs_input_grad[_Decoder._ARG0:]
         sinks = ctx.sinks or {}
 
         def new(t, want, key=None):
@@ -144,12 +176,12 @@ class _Decoder(torch.autograd.Function):
                 return sk
             return torch.empty_like(t)
 
-        g_coords, g_theta, g_dx, g_z = new(coords, ng[3]), new(theta, ng[5]), new(dx, ng[6]), new(z, ng[7] and spec.latent_dim > 0)
-        g_cw, g_cb = new(coord_w, ng[8], "coord_w"), new(coord_b, ng[9], "coord_b")
-        g_lw = new(latent_w, ng[10] and spec.latent_dim > 0, "latent_w")
-        g_bw = new(bilinear_w, ng[11] and bil, "bilinear_w")
-        g_ow, g_ob = new(out_w, ng[12], "out_w"), new(out_b, ng[13], "out_b")
-        g_hidden = tuple(new(h, ng[14 + i], "hidden%d" % i) for i, h in enumerate(hidden))
+        g_coords, g_theta, g_dx, g_z = new(coords, ng[0]), new(theta, ng[2]), new(dx, ng[3]), new(z, ng[4] and spec.latent_dim > 0)
+        g_cw, g_cb = new(coord_w, ng[5], "coord_w"), new(coord_b, ng[6], "coord_b")
+        g_lw = new(latent_w, ng[7] and spec.latent_dim > 0, "latent_w")
+        g_bw = new(bilinear_w, ng[8] and bil, "bilinear_w")
+        g_ow, g_ob = new(out_w, ng[9], "out_w"), new(out_b, ng[10], "out_b")
+        g_hidden = tuple(new(h, ng[11 + i], "hidden%d" % i) for i, h in enumerate(hidden))
         grads = _fill_params(_lib.Params(), g_cw, g_cb, g_lw, g_bw, g_ow, g_ob, g_hidden)
         pg = _lib.PoseGrads()
         pg.dcoords, pg.dtheta, pg.ddx = _p(g_coords), _p(g_theta), _p(g_dx)
@@ -157,10 +189,11 @@ class _Decoder(torch.autograd.Function):
         ws = _buf(device, ws_bytes, "ws")
         with torch.cuda.device(device):
             _lib.check(L.svae_decoder_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
-                                               logits.data_ptr(), dy.data_ptr(), None, ctx.saved_buf.data_ptr(),
+                                               logits.data_ptr(), dy.data_ptr(), _p(dy_scale), ctx.saved_buf.data_ptr(),
                                                ctypes.byref(grads), _p(g_z), ctypes.byref(pg), ws.data_ptr(), ws.numel(),
                                                _stream(device)))
         ctx.saved_buf = None
+        ctx.dll = None
         ready = sinks.get("__ready__")   # dp.TrainStep: every decoder gradient is now enqueued -> start its all-reduce
         if ready is not None:
             ready()
@@ -170,18 +203,20 @@ class _Decoder(torch.autograd.Function):
             (it would clone the view and, were .grad the same view, add it to itself)."""
             return None if (t is not None and sinks.get(key) is t) else t
 
-        return (None, None, None, g_coords, None, g_theta, g_dx, g_z, ret(g_cw, "coord_w"), ret(g_cb, "coord_b"),
+        return (None, None, None, None, g_coords, None, g_theta, g_dx, g_z, ret(g_cw, "coord_w"), ret(g_cb, "coord_b"),
                 ret(g_lw, "latent_w"), ret(g_bw, "bilinear_w"), ret(g_ow, "out_w"), ret(g_ob, "out_b")) + \
             tuple(ret(h, "hidden%d" % i) for i, h in enumerate(g_hidden))
 
 
-def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, sinks=None):
-    """Returns (y, logits), each (B, N, n_out).  Exactly one of coords / grid is given.
+def decoder(spec, B, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, sinks=None,
+            bce_target=None):
+    """Returns (y, logits), each (B, N, n_out) -- and, with bce_target (B, N, n_out), also the per-image Bernoulli
+    log-likelihood (B) computed inside the same call.  Exactly one of coords / grid is given.
     sinks: optional {name: tensor} of preallocated parameter-gradient buffers (names coord_w, coord_b,
     latent_w, bilinear_w, out_w, out_b, hidden0, hidden1, ...) the backward kernels write into; the entry
     "__ready__", if present, is a callable invoked once the backward launch sequence has been enqueued."""
-    return _Decoder.apply(spec, B, sinks, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b,
-                          *hidden)
+    return _Decoder.apply(spec, B, sinks, bce_target, coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w,
+                          out_b, *hidden)
 
 
 class _Latent(torch.autograd.Function):
