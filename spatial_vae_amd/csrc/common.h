@@ -219,4 +219,16 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// sum over a block of up to 1024 threads (a whole number of waves); result valid in every thread.  red: 16 floats.
+__device__ __forceinline__ float block_sum_waves(float v, float* red) {
+    v = wave_sum32(v);
+    v += __shfl_xor(v, 32);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (unsigned w = 0; w < (blockDim.x >> 6); ++w) s += red[w];
+    return s;
+}
+
 }  // namespace svae

@@ -197,14 +197,14 @@ __global__ void logits_finish_kernel(const float* __restrict__ lpart, const floa
 // A4's last kernel): one block per image sums the partial logits, applies bias + Sigmoid, writes y (and the logits) and, from
 // the SAME fp32 sigmoid value torch would see, the clamped log terms of F.binary_cross_entropy -- loglik[b] --
 // and d(loglik_b)/d(y) -- dll -- exactly as bce_kernel computes them from y in a second pass.
-__global__ void __launch_bounds__(256) logits_finish_bce_kernel(const float* __restrict__ lpart, const float* __restrict__ out_b,
+__global__ void __launch_bounds__(1024) logits_finish_bce_kernel(const float* __restrict__ lpart, const float* __restrict__ out_b,
                                                                 const float* __restrict__ target, float* __restrict__ y,
                                                                 float* __restrict__ logits, float* __restrict__ loglik,
                                                                 float* __restrict__ dll, RowGeo g, int C, int nblk, long Mp) {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int b = blockIdx.x;
     float acc = 0.0f;
-    for (int i = threadIdx.x; i < g.N; i += 256) {
+    for (int i = threadIdx.x; i < g.N; i += blockDim.x) {   // 1024 threads: one pixel each at 28 x 28 (a single round trip)
         const long m = (long)b * g.Npad + i;
         const long t = (long)b * g.N + i;
         for (int c = 0; c < C; ++c) {
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) logits_finish_bce_kernel(const float* __r
             if (dll) dll[t * C + c] = -(s - tg) / fmaxf((1.0f - s) * s, 1e-12f);
         }
     }
-    acc = block_sum256(acc, red);
+    acc = block_sum_waves(acc, red);
     if (threadIdx.x == 0) loglik[b] = acc;
 }
 
