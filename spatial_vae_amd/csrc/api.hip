@@ -283,57 +283,6 @@ struct Scope {  // brackets the launches issued during its lifetime
     }
 };
 
-// A second lane for small kernels that nothing on the caller's stream needs until the call's end -- the fixed-order
-// reductions of the weight-gradient partials (out_bwd_reduce, wgrad_reduce: ~35 us at BASELINE cfg 2) run UNDER the
-// data-gradient GEMM instead of in front of it.  Fork / join with events, so the contract of include/svae.h holds: all work
-// of a call is ordered after the caller's earlier work on `stream` and before its later work.  One side stream per process,
-// created at first use (the only object this library ever creates besides profiling events); SVAE_SIDE_LANE=0 keeps
-// everything on the caller's stream.  Works under stream capture (the side stream joins the capture and is joined back).
-struct SideLane {
-    hipStream_t main, side;
-    hipEvent_t fork_ev, join_ev;
-    bool on, used;
-    static bool enabled() {
-        static const bool e = [] { const char* v = getenv("SVAE_SIDE_LANE"); return !(v && v[0] == '0'); }();
-        return e;
-    }
-    explicit SideLane(hipStream_t m) : main(m), side(m), on(false), used(false) {
-        if (!enabled()) return;
-        static std::mutex mu;
-        static hipStream_t g_side = nullptr;
-        static std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return;
-        if (pool.empty()) {
-            hipEvent_t a, b;
-            if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) return;
-            if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(a); return; }
-            pool.emplace_back(a, b);
-        }
-        // a hipStreamWaitEvent captures the record made before it; re-recording the same event objects in a later call does
-        // not disturb waits already enqueued, so one pair per process serves every call
-        fork_ev = pool[0].first;
-        join_ev = pool[0].second;
-        side = g_side;
-        on = true;
-    }
-    // everything enqueued on `main` so far is visible to what follows on lane()
-    void fork() {
-        if (!on) return;
-        (void)hipEventRecord(fork_ev, main);
-        (void)hipStreamWaitEvent(side, fork_ev, 0);
-        used = true;
-    }
-    hipStream_t lane() const { return on ? side : main; }
-    // what follows on `main` sees everything enqueued on the lane so far
-    void join() {
-        if (!on || !used) return;
-        (void)hipEventRecord(join_ev, side);
-        (void)hipStreamWaitEvent(main, join_ev, 0);
-        used = false;
-    }
-};
-
 int launch_status(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SVAE_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -819,7 +768,6 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     const PoseArgs pa = pose_args(pose);
     const int resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
     // the packed weights, first-layer tables and poses were left in `saved` by the forward call (make_plan)
-    SideLane lane(st);
     // fp16x3: the data gradient of the last hidden layer runs on the f16 pipe (bounded act', contraction multiple of 64)
     const char* fuse_env0 = getenv("SVAE_FUSE_OUT");
     const bool split_bwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0 &&
@@ -853,9 +801,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         const int nparts = g.act == SVAE_ACT_TANH ? launch_out_bwd_split_a<SVAE_ACT_TANH>(g, pl, alast, p, dh32, st)
                                                   : launch_out_bwd_split_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, dh32, st);
         ob_nparts = nparts;
-        lane.fork();
-        Scope prof(K_SMALL_BWD, lane.lane());
-        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, lane.lane(), pl.wpart, pl.bpart,
+        Scope prof(K_SMALL_BWD, st);
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, st, pl.wpart, pl.bpart,
                            grads->out_w, grads->out_b, g.C, g.H, g.Hp, nparts);
     } else if (!fused_out) {
         const float* alast = pl.act[g.L - 1];
@@ -865,9 +812,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             case SVAE_ACT_RELU: launch_out_bwd_a<SVAE_ACT_RELU>(g, pl, alast, p, pl.dh[cur], st); break;
             default: launch_out_bwd_a<SVAE_ACT_SIGMOID>(g, pl, alast, p, pl.dh[cur], st); break;
         }
-        lane.fork();
-        Scope prof(K_SMALL_BWD, lane.lane());
-        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, lane.lane(), pl.wpart, pl.bpart,
+        Scope prof(K_SMALL_BWD, st);
+        hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, st, pl.wpart, pl.bpart,
                            grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.ob_chunks * 2);
     }
 
@@ -879,7 +825,6 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         // (SVAE_SPLIT_CHAIN=0: only the last hidden layer)
         const bool split_here = split_bwd && (l == g.L - 1 || split_chain_on());
         if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1]) {
-            lane.join();   // L > 2: the previous layer's reduce has read the slabs this launch overwrites
             WgradArgs w;
             w.dh = last ? pl.act[l] : pl.dh[cur];
             w.aprev = pl.act[l - 1];
@@ -900,9 +845,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                 w.S = (xcd_grid && nb2 > 1 && pl.wg_S % 8 == 0) ? pl.wg_S : 0;
                 launch_wgrad(w, w.S ? dim3(nb2 * pl.wg_S) : dim3(nb2, pl.wg_S), last ? g.C : 0, st);
             }
-            // the fixed-order sum of the split slabs runs on the side lane, under this layer's data-gradient GEMM
-            lane.fork();
-            hipStream_t ls = lane.lane();
+            hipStream_t ls = st;
             Scope prof(K_WGRAD_REDUCE, ls);
             const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)g.H * g.H + 63) / 64)), dim3(256), 0, ls, pl.slab, pl.bslab,
@@ -979,7 +922,6 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                    g.N);
         }
     }
-    lane.join();
     return launch_status("svae_decoder_backward");
 }
 

@@ -292,9 +292,6 @@ class TrainStep(object):
             base = getattr(elbo, "_base", None)           # ops.elbo_head returns views of one (elbo, log_p, kl) vector
             vec = base if (base is not None and base.numel() == 3) else torch.stack([out[0], out[1], out[2]])
             torch.mul(vec.detach(), float(weight), out=self.grads.tail)
-            if self._side is not None:
-                from .ops import grad_lane_join
-                grad_lane_join(self.device)     # the encoder's weight gradients were written on ops' side stream
         else:
             self.grads.tail.zero_()
         self._reduce()

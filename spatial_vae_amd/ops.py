@@ -301,32 +301,6 @@ def elbo_head(loglik, kl_b):
     return _ElboHead.apply(loglik, kl_b)
 
 
-# ---- a second stream for gradient kernels nothing downstream waits for -----------------------------------------------------
-# In the encoder's backward pass only dx = dy W feeds the next node; dW = dy^T x and db = colsum(dy) are consumed by the
-# optimiser alone.  They are tiny launches (16-125 workgroups), so on the compute stream each of them idles most of the chip
-# for ~5-12 us; on a side stream they run beside the dx chain.  Whoever consumes the sinks (dp.TrainStep, before the all-reduce
-# and Adam) calls grad_lane_join().  SVAE_SIDE_LANE=0 keeps everything on one stream.
-_grad_lanes = {}
-_GRAD_LANE_ON = __import__("os").environ.get("SVAE_SIDE_LANE", "1") != "0"
-
-
-def _grad_lane(device):
-    if not _GRAD_LANE_ON or torch.cuda.is_current_stream_capturing():
-        return None
-    lane = _grad_lanes.get(device)
-    if lane is None:
-        lane = _grad_lanes[device] = [torch.cuda.Stream(device), False]
-    return lane
-
-
-def grad_lane_join(device):
-    """Make the current stream wait for the gradient kernels issued on the side stream (no-op if none were)."""
-    lane = _grad_lanes.get(device)
-    if lane is not None and lane[1]:
-        torch.cuda.current_stream(device).wait_stream(lane[0])
-        lane[1] = False
-
-
 class _SinkLinear(torch.autograd.Function):
     """y = x W^T + b; the backward pass writes dW and db straight into caller-owned gradient views (slices of the flat
     buffer of dp.FlatGrads) with torch.mm(out=) / torch.sum(out=) instead of returning tensors that autograd would then
@@ -342,27 +316,13 @@ class _SinkLinear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         sink_w, sink_b = ctx.sinks
-        dx = dy.mm(weight) if ctx.needs_input_grad[0] else None      # the only product the next node waits for
-
-        def sink_grads():
-            torch.mm(dy.t(), x, out=sink_w)
-            if dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and sink_b.is_contiguous():
-                with torch.cuda.device(dy.device):   # column sums in ~3 us (ATen's reduce kernel takes 13 us for 256 x 500)
-                    _lib.check(_lib.lib().svae_colsum(dy.data_ptr(), dy.size(0), dy.size(1), sink_b.data_ptr(), _stream(dy.device)))
-            else:
-                torch.sum(dy, 0, out=sink_b)
-
-        lane = _grad_lane(dy.device) if dy.is_cuda else None
-        if lane is None:
-            sink_grads()
+        dx = dy.mm(weight) if ctx.needs_input_grad[0] else None
+        torch.mm(dy.t(), x, out=sink_w)
+        if dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and sink_b.is_contiguous():
+            with torch.cuda.device(dy.device):   # column sums in ~3 us (ATen's reduce kernel takes 13 us for 256 x 500)
+                _lib.check(_lib.lib().svae_colsum(dy.data_ptr(), dy.size(0), dy.size(1), sink_b.data_ptr(), _stream(dy.device)))
         else:
-            side = lane[0]
-            side.wait_stream(torch.cuda.current_stream(dy.device))
-            with torch.cuda.stream(side):
-                sink_grads()
-            dy.record_stream(side)      # the allocator must not recycle these while the side stream still reads them
-            x.record_stream(side)
-            lane[1] = True
+            torch.sum(dy, 0, out=sink_b)
         return dx, None, None, None, None
 
 
