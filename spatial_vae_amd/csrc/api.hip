@@ -118,6 +118,25 @@ bool split_a0_fragments_only(const Geo& g) {
            !(g.flags & SVAE_FLAG_RESID);
 }
 
+// Output-layer backward.  SVAE_FUSE_OUT unset: the rank-1 fused form wherever it applies (one output channel, tanh / sigmoid,
+// no residual, at least one hidden GEMM, fp32-MFMA mode) -- both GEMMs of the last hidden layer read a_{L-1} itself, no dh_{L-1}
+// plane and no out_bwd pass -- and the streaming out_bwd pass elsewhere; "1": the generic fused form for any channel count
+// (slower than the streaming pass on the fp32 MFMA: see wgrad_kernel); "0": always the streaming pass.
+int fuse_out_mode() {
+    const char* e = getenv("SVAE_FUSE_OUT");
+    if (!e) return 2;
+    return e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
+}
+bool split_active(const Geo& g) {
+    return split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0;
+}
+// decided from the descriptor alone: the forward call packs the data-gradient weights of the last hidden layer with their
+// rows scaled by w_o when (and only when) the backward call will take the rank-1 form
+bool rank1_out(const Geo& g) {
+    return fuse_out_mode() == 2 && !split_active(g) && g.C == 1 && g.L >= 2 && !(g.flags & SVAE_FLAG_RESID) &&
+           (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID);
+}
+
 Plan make_plan(const Geo& g, void* saved, void* ws) {
     Plan p;
     const size_t MH = (size_t)g.Mp * g.Hp;
@@ -315,14 +334,14 @@ void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const Po
                        pl.tab, pl.posebuf, pa, g.B, g.H, g.Hp, g.Zd, g.in_dim);
     for (int l = 0; l + 1 < g.L; ++l)
         hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks_for((long)g.Hp * g.Hp)), dim3(256), 0, st, p->hidden_w[l],
-                           pl.wf[l], pl.wb[l], g.H, g.Hp);
+                           pl.wf[l], pl.wb[l], g.H, g.Hp, (l == g.L - 2 && rank1_out(g)) ? p->out_w : (const float*)nullptr);
 }
 
-template <int NT, bool DGRAD, bool RESID, bool FIRST, bool LASTD, int CF = 0>
+template <int NT, bool DGRAD, bool RESID, bool FIRST, int LASTD, int CF = 0>
 void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
-    // weight buffers, plus the W_o table (max channels x max width) behind them for LASTD
-    constexpr int kLds = DenseCfg<NT>::LDS_BYTES + (LASTD ? SVAE_MAX_OUT * 4096 * 4 : 0);
-    const int lds = DenseCfg<NT>::LDS_BYTES + (LASTD ? SVAE_MAX_OUT * a.Hp * 4 : 0);
+    // weight buffers, plus the W_o table (max channels x max width) behind them for the generic LASTD form
+    constexpr int kLds = DenseCfg<NT>::LDS_BYTES + (LASTD == 1 ? SVAE_MAX_OUT * 4096 * 4 : 0);
+    const int lds = DenseCfg<NT>::LDS_BYTES + (LASTD == 1 ? SVAE_MAX_OUT * a.Hp * 4 : 0);
     static bool attr_set = false;  // LDS beyond 64 KiB needs the opt-in attribute once per kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_kernel<NT, DGRAD, RESID, FIRST, LASTD, CF>),
@@ -333,16 +352,16 @@ void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
 }
 
 template <int NT, bool DGRAD>
-void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
+void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
     if constexpr (!DGRAD && NT <= 4) {  // forward of the last hidden layer with the output layer's logits in the epilogue
         if (cf == 1) {
-            if (a.resid) launch_dense_ntr<NT, false, true, false, false, 1>(a, grid, st);
-            else launch_dense_ntr<NT, false, false, false, false, 1>(a, grid, st);
+            if (a.resid) launch_dense_ntr<NT, false, true, false, 0, 1>(a, grid, st);
+            else launch_dense_ntr<NT, false, false, false, 0, 1>(a, grid, st);
             return;
         }
         if (cf == 2) {
-            if (a.resid) launch_dense_ntr<NT, false, true, false, false, 2>(a, grid, st);
-            else launch_dense_ntr<NT, false, false, false, false, 2>(a, grid, st);
+            if (a.resid) launch_dense_ntr<NT, false, true, false, 0, 2>(a, grid, st);
+            else launch_dense_ntr<NT, false, false, false, 0, 2>(a, grid, st);
             return;
         }
     }
@@ -351,18 +370,24 @@ void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first =
     // not exist: dense_nt_first() caps the column tiles at 4 for them.
     if constexpr (DGRAD && NT <= 4) {
       if (first || lastd) {
-        if (lastd) {  // never with a residual (checked by the caller)
-            if (first) launch_dense_ntr<NT, true, false, true, true>(a, grid, st);
-            else launch_dense_ntr<NT, true, false, false, true>(a, grid, st);
+        if (lastd == 2) {        // rank-1 form (tanh), never with a residual (checked by the caller)
+            if (first) launch_dense_ntr<NT, true, false, true, 2>(a, grid, st);
+            else launch_dense_ntr<NT, true, false, false, 2>(a, grid, st);
+        } else if (lastd == 3) {  // rank-1 form (sigmoid)
+            if (first) launch_dense_ntr<NT, true, false, true, 3>(a, grid, st);
+            else launch_dense_ntr<NT, true, false, false, 3>(a, grid, st);
+        } else if (lastd == 1) {  // generic form, never with a residual
+            if (first) launch_dense_ntr<NT, true, false, true, 1>(a, grid, st);
+            else launch_dense_ntr<NT, true, false, false, 1>(a, grid, st);
         } else {
-            if (a.resid) launch_dense_ntr<NT, true, true, true, false>(a, grid, st);
-            else launch_dense_ntr<NT, true, false, true, false>(a, grid, st);
+            if (a.resid) launch_dense_ntr<NT, true, true, true, 0>(a, grid, st);
+            else launch_dense_ntr<NT, true, false, true, 0>(a, grid, st);
         }
         return;
       }
     }
-    if (a.resid) launch_dense_ntr<NT, DGRAD, true, false, false>(a, grid, st);
-    else launch_dense_ntr<NT, DGRAD, false, false, false>(a, grid, st);
+    if (a.resid) launch_dense_ntr<NT, DGRAD, true, false, 0>(a, grid, st);
+    else launch_dense_ntr<NT, DGRAD, false, false, 0>(a, grid, st);
 }
 
 // column tiles accumulated per pass: the widest that divides the layer, unless SVAE_DENSE_NT caps it
@@ -541,7 +566,7 @@ void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const flo
 }
 
 template <bool DGRAD>
-void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, bool lastd = false, int cf = 0) {
+void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
     const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
@@ -557,19 +582,28 @@ void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first =
     }
 }
 
-template <int CL>
+template <int CL, int R1 = 0>
 void launch_wgrad_c(const WgradArgs& w, dim3 grid, hipStream_t st) {
     static bool attr_set = false;  // 144 KiB of LDS (4 waves x 4 ring slots x 9 KiB) needs the opt-in
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<CL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<CL, R1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kWgradLdsBytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<CL>), grid, dim3(256), kWgradLdsBytes, st, w);
+    hipLaunchKernelGGL((wgrad_kernel<CL, R1>), grid, dim3(256), kWgradLdsBytes, st, w);
 }
 
-void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, hipStream_t st) {
+// cl > 0: the LASTW forms (dh formed from a_{L-1} in registers); r1: the rank-1 form (cl == 1), 1 = tanh, 2 = sigmoid
+void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, int r1, hipStream_t st) {
     Scope prof(K_WGRAD, st);
+    if (r1 == 1) {
+        launch_wgrad_c<1, 1>(w, grid, st);
+        return;
+    }
+    if (r1 == 2) {
+        launch_wgrad_c<1, 2>(w, grid, st);
+        return;
+    }
     switch (cl) {
         case 1: launch_wgrad_c<1>(w, grid, st); break;
         case 2: launch_wgrad_c<2>(w, grid, st); break;
@@ -709,7 +743,7 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
         a.do_p = nullptr; a.out_w = p->out_w; a.C = g.C;
         a.lpart = pl.dfpart;  // free during the forward pass; nblk * C * Mp <= ntile * 2 * Mp floats
-        launch_dense<false>(g, a, st, false, false, (fuse_logits && l == g.L - 1) ? g.C : 0);
+        launch_dense<false>(g, a, st, false, 0, (fuse_logits && l == g.L - 1) ? g.C : 0);
     }
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
@@ -769,9 +803,9 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     const int resid = (g.flags & SVAE_FLAG_RESID) ? 1 : 0;
     // the packed weights, first-layer tables and poses were left in `saved` by the forward call (make_plan)
     // fp16x3: the data gradient of the last hidden layer runs on the f16 pipe (bounded act', contraction multiple of 64)
-    const char* fuse_env0 = getenv("SVAE_FUSE_OUT");
-    const bool split_bwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0 &&
-                           g.L >= 2 && !(fuse_env0 && fuse_env0[0] == '1');
+    const int fmode = fuse_out_mode();
+    const bool split_bwd = split_active(g) && g.L >= 2 && fmode != 1;
+    const bool r1 = rank1_out(g);   // the forward call packed this layer's data-gradient weights for it
 
     // d(loss)/d(logits) in padded row space (pad rows exactly zero)
     {
@@ -788,9 +822,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     // GEMMs of the last hidden layer form it from a_{L-1} on the fly (LASTW / LASTD) and the weight-gradient
     // kernel also produces dW_o, db_o.  Otherwise: one streaming pass (out_bwd_kernel).
     int cur = 0;
-    const char* fuse_env = getenv("SVAE_FUSE_OUT");  // opt-in: slower on fp32 MFMA (see wgrad_kernel), saves a 419 MB plane
-    const bool fused_out = fuse_env && fuse_env[0] == '1' && g.L >= 2 && !resid &&
-                           (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]);
+    // rank-1 form by default where it applies; the generic fused form is opt-in (slower on fp32 MFMA, saves a 419 MB plane)
+    const bool fused_out = r1 || (fmode == 1 && g.L >= 2 && !resid && (grads->hidden_w[g.L - 2] || grads->hidden_b[g.L - 2]));
     // fp16x3 with both GEMMs of the last hidden layer on the f16 pipe: dh leaves out_bwd in their operand forms
     int ob_nparts = 0;
     static const bool ob_env = [] { const char* e = getenv("SVAE_SPLIT_OB"); return !(e && e[0] == '0'); }();
@@ -824,7 +857,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         // fp16x3 runs down the stack: every split data gradient leaves the scale of its result for the layer below
         // (SVAE_SPLIT_CHAIN=0: only the last hidden layer)
         const bool split_here = split_bwd && (l == g.L - 1 || split_chain_on());
-        if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1]) {
+        // the fused forms also get dW_o / db_o from this layer's weight-gradient kernel
+        if (grads->hidden_w[l - 1] || grads->hidden_b[l - 1] || (last && (grads->out_w || grads->out_b))) {
             WgradArgs w;
             w.dh = last ? pl.act[l] : pl.dh[cur];
             w.aprev = pl.act[l - 1];
@@ -843,14 +877,15 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                 static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
                 const int nb2 = pl.wg_nblk1 * pl.wg_nblk1;
                 w.S = (xcd_grid && nb2 > 1 && pl.wg_S % 8 == 0) ? pl.wg_S : 0;
-                launch_wgrad(w, w.S ? dim3(nb2 * pl.wg_S) : dim3(nb2, pl.wg_S), last ? g.C : 0, st);
+                launch_wgrad(w, w.S ? dim3(nb2 * pl.wg_S) : dim3(nb2, pl.wg_S), last ? g.C : 0,
+                             (last && r1) ? (g.act == SVAE_ACT_TANH ? 1 : 2) : 0, st);
             }
             hipStream_t ls = st;
             Scope prof(K_WGRAD_REDUCE, ls);
             const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)g.H * g.H + 63) / 64)), dim3(256), 0, ls, pl.slab, pl.bslab,
                                grads->hidden_w[l - 1], db_elsewhere ? (float*)nullptr : grads->hidden_b[l - 1], g.H, g.Hp,
-                               pl.wg_S);
+                               pl.wg_S, (last && r1) ? p->out_w : (const float*)nullptr);
             if (db_elsewhere && grads->hidden_b[l - 1])
                 hipLaunchKernelGGL(colsum_reduce_kernel, dim3(g.Hp / 32), dim3(256), 0, ls, pl.hbpart, grads->hidden_b[l - 1],
                                    g.H, g.Hp, ob_nparts);
@@ -877,7 +912,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa,
                                split_ob && l == g.L - 1, st);
         else
-            launch_dense<true>(g, a, st, fused_first, last);
+            launch_dense<true>(g, a, st, fused_first, last ? (r1 ? (g.act == SVAE_ACT_TANH ? 2 : 3) : 1) : 0);
         cur ^= 1;
     }
 

@@ -54,7 +54,11 @@ struct DenseArgs {
     long Mp;
     int N, Timg;
     // LASTD (data gradient out of the LAST hidden layer, no residual): `in` is a_{L-1} itself and the row
-    // operand dh_{L-1}[m][n] = (sum_c do[m][c] W_o[c][n]) * act'(a_{L-1}[m][n]) is formed in registers
+    // operand dh_{L-1}[m][n] = (sum_c do[m][c] W_o[c][n]) * act'(a_{L-1}[m][n]) is formed in registers.
+    //   LASTD == 1: any C, exactly that expression per element (LDS table of W_o; ~10 VALU/LDS ops per element: +21 %).
+    //   LASTD == 2 (tanh) / 3 (sigmoid): ONE output channel -- dh_{L-1} = diag(do) P diag(w_o) with P = act'(a_{L-1}), a
+    //               rank-1 scaling of P, so the GEMM runs on P itself (one fma per element) against weights whose rows
+    //               were scaled by w_o when they were packed, and the epilogue multiplies each row by do[m].
     const float* do_p;   // [C][Mp] d(loss)/d(logits), zero on pad rows
     const float* out_w;  // (C, H)
     int C;
@@ -189,11 +193,11 @@ struct DenseOcc {
     static constexpr int value = NT == 16 ? 1 : (NT == 8 || FUSED) ? 2 : SVAE_NT4_WAVES;
 };
 
-template <int NT, bool DGRAD, bool RESID, bool FIRST = false, bool LASTD = false, int CF = 0>
-__global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOcc<NT, (FIRST || LASTD)>::value)) void dense_kernel(DenseArgs a) {
+template <int NT, bool DGRAD, bool RESID, bool FIRST = false, int LASTD = 0, int CF = 0>
+__global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOcc<NT, (FIRST || LASTD != 0)>::value)) void dense_kernel(DenseArgs a) {
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(CF == 0 || (!DGRAD && CF <= 2), "CF is a forward epilogue for at most two output channels");
-    static_assert(!LASTD || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
+    static_assert(LASTD == 0 || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using Cfg = DenseCfg<NT>;
     constexpr int NB = Cfg::NB, G = Cfg::G, CHUNK = Cfg::CHUNK, NINSTR = Cfg::NINSTR;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
         float* wo_lds = smem + 2 * CHUNK;
         const ActCoef acoef = act_coef(a.act);
         float dlog[SVAE_MAX_OUT] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (LASTD) {
+        if (LASTD == 1) {
             for (int i = threadIdx.x; i < SVAE_MAX_OUT * Hp; i += 256) {
                 const int c = i / Hp, n = i - c * Hp;
                 wo_lds[i] = (c < a.C && n < a.H) ? a.out_w[c * a.H + n] : 0.0f;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                     if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
                 }
                 float sdo[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-                if (LASTD) {  // sum_c dlog_c * W_o[c][k] for this octet's four k-steps (k = 8o + 4h + e)
+                if (LASTD == 1) {  // sum_c dlog_c * W_o[c][k] for this octet's four k-steps (k = 8o + 4h + e)
                     sdo[0] = sdo[1] = sdo[2] = sdo[3] = 0.0f;
 #pragma unroll
                     for (int cc = 0; cc < SVAE_MAX_OUT; ++cc) {
@@ -339,7 +343,11 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     wait_vm1<15 + P>(av[gl][e]);
-                    const float x = LASTD ? sdo[e] * act_grad_rt(acoef, av[gl][e]) : av[gl][e];
+                    // rank-1 forms: act'(a) in ONE fma -- tanh 1 - a^2 (LASTD == 2), sigmoid a - a^2 (LASTD == 3)
+                    const float x = LASTD == 1 ? sdo[e] * act_grad_rt(acoef, av[gl][e])
+                                    : LASTD == 2 ? __builtin_fmaf(-av[gl][e], av[gl][e], 1.0f)
+                                    : LASTD == 3 ? __builtin_fmaf(-av[gl][e], av[gl][e], av[gl][e])
+                                                 : av[gl][e];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const float4 bb = (gl & 1) ? b1[t] : b0[t];
@@ -420,6 +428,11 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                         for (int r = 0; r < 16; ++r) lp[c][r] = 0.0f;
                     }
                 }
+                float4 dq[4];  // rank-1 forms: d(loss)/d(logit) of this lane's rows 8q + 4h .. +3 (zero on pad rows)
+                if (LASTD >= 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dq[q] = *reinterpret_cast<const float4*>(a.do_p + tl * 32 + 8 * q + 4 * h);
+                }
                 const long off0 = (tl * 4 * (long)Hp + nb * NB + nl) * 8 + 4 * h;  // (q = 0, t = 0)
                 const long qstride = (long)Hp * 8;                                  // next row octet
                 float4 xa[2][4], xr[2][4];  // aux (data gradient) and residual operands of tile t / t+1
@@ -439,6 +452,7 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                             v.x += fr[q].x; v.y += fr[q].y; v.z += fr[q].z; v.w += fr[q].w;
                         }
                         v = dense_epilogue<ACT, DGRAD>(v, bias[t], fa[q]);
+                        if (LASTD >= 2) { v.x *= dq[q].x; v.y *= dq[q].y; v.z *= dq[q].z; v.w *= dq[q].w; }
                         *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = v;
                         if (CF > 0) {
 #pragma unroll
@@ -517,6 +531,7 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                                 v.x += fr.x; v.y += fr.y; v.z += fr.z; v.w += fr.w;
                             }
                             v = dense_epilogue<ACT, true>(v, 0.0f, xa[t & 1][q]);
+                            if (LASTD >= 2) { v.x *= dq[q].x; v.y *= dq[q].y; v.z *= dq[q].z; v.w *= dq[q].w; }
                             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -596,8 +611,12 @@ constexpr int kWgradLdsBytes = 4 * 4 * 9 * 1024;  // 4 waves x 4 ring slots x (8
 // CL = 0: dh comes from HBM.  CL = C (1..4): LASTW, dh_{L-1} = (sum_c do_c W_o[c]) * act'(a_{L-1}) formed from the
 // a_{L-1} fragments, with the rows of d(logits) arriving as a 9th DMA piece per octet; the waves of output
 // column-block 0 also accumulate dW_o[c][n] = sum_m do[m][c] a_{L-1}[m][n] and db_o.
-template <int CL>
+// R1 = 1 (tanh) / 2 (sigmoid), with CL == 1: the rank-1 form of LASTW -- dh_{L-1}[m][n] = do[m] act'(a[m][n]) w_o[n], so the
+// fragments only take act'(a) * do[m] (2 VALU ops per element: t = d a, then d - t a or t - t a) and the factor w_o[n],
+// constant along the contraction, is applied to row n of dW and to db[n] by wgrad_reduce_kernel (row_scale).
+template <int CL, int R1 = 0>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
+    static_assert(R1 == 0 || CL == 1, "the rank-1 form needs exactly one output channel");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nl = lane & 31, h = lane >> 5;
@@ -699,17 +718,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             float4 d[CL > 0 ? CL : 1];
 #pragma unroll
             for (int c = 0; c < CL; ++c) d[c] = *reinterpret_cast<const float4*>(dl + c * 8);
-            // dW_o / db_o partials; a clamped re-load (o >= o1) must not be accumulated twice: weight 0
-            const float wgt = (own_out && o < o1) ? 1.0f : 0.0f;
+            // dW_o / db_o partials, in the waves that own an output column tile only (wave-uniform branch around pure VALU
+            // work: 3 waves in 4 skip it); a clamped re-load (o >= o1) must not be accumulated twice: weight 0
+            if (own_out) {
+                const float wgt = (o < o1) ? 1.0f : 0.0f;
 #pragma unroll
-            for (int c = 0; c < CL; ++c) {
-                pbias[c] += wgt * ((d[c].x + d[c].y) + (d[c].z + d[c].w));
+                for (int c = 0; c < CL; ++c) {
+                    pbias[c] += wgt * ((d[c].x + d[c].y) + (d[c].z + d[c].w));
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    pw[c][t] += wgt * ((d[c].x * xa[t].x + d[c].y * xa[t].y) + (d[c].z * xa[t].z + d[c].w * xa[t].w));
+                    for (int t = 0; t < 4; ++t)
+                        pw[c][t] += wgt * ((d[c].x * xa[t].x + d[c].y * xa[t].y) + (d[c].z * xa[t].z + d[c].w * xa[t].w));
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (R1 != 0) {  // act'(a) d: t = d a, then tanh d - t a = d (1 - a^2), sigmoid t - t a = d a (1 - a)
+                    const float4 v = xa[t];
+                    const float4 tt = make_float4(d[0].x * v.x, d[0].y * v.y, d[0].z * v.z, d[0].w * v.w);
+                    xa[t] = make_float4(__builtin_fmaf(-tt.x, v.x, R1 == 1 ? d[0].x : tt.x), __builtin_fmaf(-tt.y, v.y, R1 == 1 ? d[0].y : tt.y),
+                                        __builtin_fmaf(-tt.z, v.z, R1 == 1 ? d[0].z : tt.z), __builtin_fmaf(-tt.w, v.w, R1 == 1 ? d[0].w : tt.w));
+                    continue;
+                }
                 float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int c = 0; c < CL; ++c) {
@@ -801,8 +830,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 // elements of dW; thread = (element, slab group g of 4): it sums slabs g, g+4, g+8, ... in four interleaved chains, and the
 // four groups are combined through LDS in a fixed order (deterministic).  16 independent loads per thread are in flight
 // (r01: one thread per element walked all S slabs, 4 loads in flight: 0.042 ms for 64 MB).
+// row_scale (nullable): dW row n and db[n] are multiplied by row_scale[n] (the rank-1 output-layer form: w_o[n]).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
-                                                           float* __restrict__ dW, float* __restrict__ db, int H, int Hp, int S) {
+                                                           float* __restrict__ dW, float* __restrict__ db, int H, int Hp, int S,
+                                                           const float* __restrict__ row_scale) {
     __shared__ float red[4][64];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long idx = (long)blockIdx.x * 64 + col;
@@ -825,7 +856,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
     red[grp][col] = part;
     __syncthreads();
-    if (grp == 0 && in && dW) dW[idx] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (grp == 0 && in && dW) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        dW[idx] = row_scale ? t * row_scale[idx / H] : t;
+    }
     if (db && blockIdx.x * 64 < H) {  // the first ceil(H / 64) blocks also carry 64 bias entries each
         __syncthreads();
         const int n = blockIdx.x * 64 + col;
@@ -834,7 +868,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
             for (int i = grp; i < 2 * S; i += 4) s += bslab[(long)i * Hp + n];
         red[grp][col] = s;
         __syncthreads();
-        if (grp == 0 && n < H) db[n] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        if (grp == 0 && n < H) {
+            const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+            db[n] = row_scale ? t * row_scale[n] : t;
+        }
     }
 }
 

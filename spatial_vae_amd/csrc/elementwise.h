@@ -17,14 +17,16 @@ namespace svae {
 __device__ __forceinline__ long slab_index(int contr, int out, int ntile) {
     return (((long)(contr >> 3) * ntile + (out >> 5)) * 2 + ((contr >> 2) & 1)) * 128 + (out & 31) * 4 + (contr & 3);
 }
+// wb_row_scale (nullable): the data-gradient image holds W[n][k] * wb_row_scale[n] -- the rank-1 output-layer backward
+// (dense_kernel LASTD == 2) folds w_o[n] into the weights it contracts over n.
 __global__ void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ wf, float* __restrict__ wb, int H,
-                                    int Hp) {
+                                    int Hp, const float* __restrict__ wb_row_scale) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Hp * Hp) return;
     const int n = idx / Hp, k = idx % Hp;
     const float v = (n < H && k < H) ? W[(long)n * H + k] : 0.0f;
     wf[slab_index(k, n, Hp / 32)] = v;
-    wb[slab_index(n, k, Hp / 32)] = v;
+    wb[slab_index(n, k, Hp / 32)] = (wb_row_scale && n < H) ? v * wb_row_scale[n] : v;
 }
 
 // ---------------------------------------------------------------- per-image tables

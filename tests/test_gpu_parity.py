@@ -106,10 +106,21 @@ def test_library_is_the_hip_one():
 @pytest.mark.parametrize("name", ["mnist_rt", "mnist_L3", "mnist_leaky", "mnist_sigmoid_act", "galaxy_rgb", "particles_fit_noise",
                                   "mnist_wide", "mnist_h500"])
 def test_fused_output_layer_backward_option(name, monkeypatch):
-    """SVAE_FUSE_OUT=1 forms dh_{L-1} inside the two GEMMs of the last hidden layer instead of the streaming
-    out_bwd pass (off by default: slower on fp32 MFMA); it must give the same gradients."""
+    """SVAE_FUSE_OUT=1 forms dh_{L-1} inside the two GEMMs of the last hidden layer, for any number of output channels,
+    instead of the streaming out_bwd pass (opt-in: slower on fp32 MFMA); it must give the same gradients."""
     monkeypatch.setenv("SVAE_FUSE_OUT", "1")
     test_eval_minibatch_matches_reference(name)
+
+
+@pytest.mark.parametrize("name", ["mnist_rt", "mnist_L3", "mnist_sigmoid_act", "mnist_wide", "mnist_h500", "mnist_saturated",
+                                  "particles_gauss", "particles_ctf"])
+def test_streaming_output_layer_backward_option(name, monkeypatch):
+    """The default for one output channel and a smooth activation is the rank-1 fused form (no dh_{L-1} plane: every golden
+    test of such a case runs it); SVAE_FUSE_OUT=0 forces the streaming out_bwd pass those cases took in r01 -- it stays the
+    path of every other geometry and must keep giving the same numbers."""
+    monkeypatch.setenv("SVAE_FUSE_OUT", "0")
+    test_eval_minibatch_matches_reference(name)
+    test_decoder_module_matches_reference(name)
 
 
 def test_flat_adam_matches_torch_adam():
