@@ -293,6 +293,17 @@ int svae_profile_enable(int on);
 int svae_profile_read(double* ms_total, int64_t* launches); /* arrays of SVAE_PROF_KINDS */
 const char* svae_profile_kind_name(int kind);
 
+/*
+ * Which kernel families the calls of this process have dispatched so far: the GEMM mode is a request and the plan decides
+ * per geometry (fp16x3 takes the fp32 kernels for ReLU-type activations and odd tile counts; the output-layer backward has a
+ * streaming, a split, a rank-1 and a generic fused form), so a caller -- or a test -- can tell which code actually ran.
+ * counts[path] = launches of that family since process start (or since the last read with reset != 0); svae_path_name gives
+ * the label ("dense_fp32_fwd", "dense_split_fwd", "wgrad_split", "out_bwd_rank1", ...; "" for unused slots).
+ */
+#define SVAE_PATH_KINDS 16
+int svae_path_counts(int64_t* counts, int reset); /* array of SVAE_PATH_KINDS */
+const char* svae_path_name(int path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,10 @@ def lib():
     L.svae_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     L.svae_profile_kind_name.restype = ctypes.c_char_p
     L.svae_profile_kind_name.argtypes = [ctypes.c_int]
+    L.svae_path_counts.restype = ctypes.c_int
+    L.svae_path_counts.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    L.svae_path_name.restype = ctypes.c_char_p
+    L.svae_path_name.argtypes = [ctypes.c_int]
     if L.svae_abi_version() != ABI_VERSION:
         raise RuntimeError("spatial_vae_amd: %s has ABI version %d, this binding needs %d -- rebuild it"
                            % (path, L.svae_abi_version(), ABI_VERSION))
@@ -151,3 +155,15 @@ def profile_read():
     cnt = (ctypes.c_int64 * PROF_KINDS)()
     check(L.svae_profile_read(ms, cnt))
     return {L.svae_profile_kind_name(k).decode(): (ms[k], cnt[k]) for k in range(PROF_KINDS) if cnt[k]}
+
+
+PATH_KINDS = 16
+
+
+def path_counts(reset=False):
+    """{kernel family: launches} dispatched by this process (svae_path_counts): tells a run of the fp16x3 split kernels, the
+    rank-1 output-layer backward etc. from a fallback to the plain fp32 kernels."""
+    L = lib()
+    arr = (ctypes.c_int64 * PATH_KINDS)()
+    check(L.svae_path_counts(arr, 1 if reset else 0))
+    return {L.svae_path_name(i).decode(): int(arr[i]) for i in range(PATH_KINDS) if L.svae_path_name(i)}

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -272,6 +273,18 @@ enum Kind { K_PREPARE = 0, K_LAYER0_FWD, K_DENSE_FWD, K_OUT_FWD, K_DLOGITS, K_OU
 const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense_fwd", "out_fwd", "dlogits", "out_bwd",
                                                  "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
                                                  "gaussian", "latent", "adam", "augment"};
+// which kernel family a call actually dispatched (svae_path_counts): the GEMM mode is a request, the plan decides per
+// geometry (fp16x3 falls back to the fp32 kernels for unbounded activations and odd tile counts), and a test must be able
+// to tell a run of the split kernels from a silent fallback
+enum Path { P_DENSE_FP32_FWD = 0, P_DENSE_FP32_DGRAD, P_WGRAD_FP32, P_DENSE_SPLIT_FWD, P_DENSE_SPLIT_DGRAD, P_WGRAD_SPLIT,
+            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_COUNT };
+const char* const kPathNames[SVAE_PATH_KINDS] = {"dense_fp32_fwd", "dense_fp32_dgrad", "wgrad_fp32", "dense_split_fwd",
+                                                  "dense_split_dgrad", "wgrad_split", "out_bwd_stream", "out_bwd_split",
+                                                  "out_bwd_rank1", "out_bwd_fused_generic", "", "", "", "", "", ""};
+static_assert(P_COUNT <= SVAE_PATH_KINDS, "svae_path_counts array too small");
+std::atomic<long long> g_path[SVAE_PATH_KINDS];
+inline void took(int path) { g_path[path].fetch_add(1, std::memory_order_relaxed); }
+
 struct ProfRec { hipEvent_t a, b; int kind; };
 int g_prof_level = 0;  // 0 off, 1 = the three MFMA GEMM kernels only, 2 = every kernel
 std::vector<ProfRec> g_prof_used, g_prof_free;
@@ -454,6 +467,7 @@ dim3 split_grid(const Geo& g, int nt, int waves = kSplitWaves) {  // see dense_s
 // forward hidden layer in fp16x3 mode: split the weights and the row operand, then the f16-MFMA GEMM
 void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float* W, const float* bias, float* out, bool resid,
                       int cf, const float* out_w, bool rows_ready, hipStream_t st) {
+    took(P_DENSE_SPLIT_FWD);
     {
         Scope prof(K_PREPARE, st);
         split_weights(g, pl, W, 0, st);
@@ -479,6 +493,7 @@ void launch_split_fwd(const Geo& g, const Plan& pl, const float* in, const float
 // data gradient of the LAST hidden layer in fp16x3 mode: dh (fp32, scaled by pl.gscale) -> split rows, W^T -> split weights
 void launch_split_dgrad(const Geo& g, const Plan& pl, const float* dh, const float* W, const float* aux, float* out, bool resid,
                         bool first, const PoseArgs& pa, bool rows_ready, hipStream_t st) {
+    took(P_DENSE_SPLIT_DGRAD);
     {
         Scope prof(K_PREPARE, st);
         split_weights(g, pl, W, 1, st);
@@ -528,6 +543,7 @@ int launch_out_bwd_split_ac(const Geo& g, const Plan& pl, const float* a, const 
 }
 template <int ACT>
 int launch_out_bwd_split_a(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh32, hipStream_t st) {
+    took(P_OUT_BWD_SPLIT);
     switch (g.C) {
         case 1: return launch_out_bwd_split_ac<ACT, 1>(g, pl, a, p, dh32, st);
         case 2: return launch_out_bwd_split_ac<ACT, 2>(g, pl, a, p, dh32, st);
@@ -539,6 +555,7 @@ int launch_out_bwd_split_a(const Geo& g, const Plan& pl, const float* a, const s
 // weight gradient of the LAST hidden layer in fp16x3 mode (operands converted to column fragments first)
 void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const float* aprev, const uint4* aprev_cols,
                         bool cols_ready, hipStream_t st) {
+    took(P_WGRAD_SPLIT);
     {
         Scope prof(K_PREPARE, st);
         if (!cols_ready)
@@ -567,6 +584,8 @@ void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const flo
 
 template <bool DGRAD>
 void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
+    took(DGRAD ? P_DENSE_FP32_DGRAD : P_DENSE_FP32_FWD);
+    if (lastd) took(lastd == 1 ? P_OUT_BWD_FUSED_GENERIC : P_OUT_BWD_RANK1);
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
     const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
@@ -595,6 +614,7 @@ void launch_wgrad_c(const WgradArgs& w, dim3 grid, hipStream_t st) {
 
 // cl > 0: the LASTW forms (dh formed from a_{L-1} in registers); r1: the rank-1 form (cl == 1), 1 = tanh, 2 = sigmoid
 void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, int r1, hipStream_t st) {
+    took(P_WGRAD_FP32);
     Scope prof(K_WGRAD, st);
     if (r1 == 1) {
         launch_wgrad_c<1, 1>(w, grid, st);
@@ -651,6 +671,7 @@ void launch_out_bwd_ac(const Geo& g, const Plan& pl, const float* a, const svae_
 }
 template <int ACT>
 void launch_out_bwd_a(const Geo& g, const Plan& pl, const float* a, const svae_params* p, float* dh, hipStream_t st) {
+    took(P_OUT_BWD_STREAM);
     switch (g.C) {
         case 1: launch_out_bwd_ac<ACT, 1>(g, pl, a, p, dh, st); break;
         case 2: launch_out_bwd_ac<ACT, 2>(g, pl, a, p, dh, st); break;
@@ -1177,5 +1198,13 @@ int svae_profile_read(double* ms_total, int64_t* launches) {
 }
 
 const char* svae_profile_kind_name(int kind) { return (kind >= 0 && kind < SVAE_PROF_KINDS) ? kKindNames[kind] : ""; }
+
+int svae_path_counts(int64_t* counts, int reset) {
+    if (!counts) return fail(SVAE_E_INVALID, "svae_path_counts: null output");
+    for (int i = 0; i < SVAE_PATH_KINDS; ++i)
+        counts[i] = reset ? (int64_t)g_path[i].exchange(0, std::memory_order_relaxed) : (int64_t)g_path[i].load(std::memory_order_relaxed);
+    return SVAE_OK;
+}
+const char* svae_path_name(int path) { return (path >= 0 && path < SVAE_PATH_KINDS) ? kPathNames[path] : ""; }
 
 }  // extern "C"
