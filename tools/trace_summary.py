@@ -31,13 +31,10 @@ def main():
     f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # the timed region = the last `steps` repetitions: find the launches of the forward GEMM and cut there
-    marks = [i for i, r in enumerate(rows) if "dense_kernel<4, false" in r["Kernel_Name"] or "dense_split_kernel<4, 0" in r["Kernel_Name"]]
-    first = marks[-steps]
-    # back up to the start of that step (the first encoder GEMM before it)
-    start_i = first
-    while start_i > 0 and "adam_kernel" not in rows[start_i - 1]["Kernel_Name"]:
-        start_i -= 1
+    # the timed region = the last `steps` repetitions; a step ends with its (single) Adam launch
+    ends = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    start_i = ends[-steps - 1] + 1 if len(ends) > steps else 0
+    rows = rows[:ends[-1] + 1]
     sel = rows[start_i:]
     t0, t1 = int(sel[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in sel)
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel)
