@@ -261,6 +261,8 @@ def build_epoch_inputs(ec):
         out["ctf"] = None
     # one noise tensor per step: epochs x minibatches
     out["r"] = [[rs.normal(size=(b, inf_dim(case))).astype(np.float32) for b in ec["batches"]] for _ in ec["z_scales"]]
+    # the noise of the evaluation pass that follows the last training epoch (eval_model draws too: train_mnist.py:174-226)
+    out["r_eval"] = [rs.normal(size=(b, inf_dim(case))).astype(np.float32) for b in ec["batches"]]
     return out
 
 

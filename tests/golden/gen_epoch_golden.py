@@ -6,8 +6,9 @@
 * epoch_*.npz -- the reference's own train_epoch (train_mnist.py:127-171; train_particles.py:151-202) driven with a list of
   minibatches instead of a DataLoader, a fresh torch.optim.Adam over p_net then q_net parameters exactly as main() builds it
   (train_mnist.py:389-392), and the noise of every step supplied by patching Tensor.normal_ (as gen_golden.py does).  Stored:
-  the (elbo, log_p, kl) of every step, the running means train_epoch returns per epoch, and every parameter after the last
-  step.  One case runs two epochs with z_scale 0 then 1 (the --z-delay schedule of train_particles.py:500-504).
+  the (elbo, log_p, kl) of every step, the running means train_epoch returns per epoch, every parameter after the last
+  step, and the running means eval_model (train_mnist.py:174-226, train_particles.py:205-245) then returns over the same
+  minibatches with the trained networks.  One case runs two epochs with z_scale 0 then 1 (the --z-delay schedule of train_particles.py:500-504).
 * vanilla_*.npz -- eval_minibatch with VanillaGenerator (models.py:135-172) as the scripts build it for --vanilla
   (rotate = translate = False; train_mnist.py:351-357, train_particles.py:446-452): elbo, log_p, kl, y_hat and the gradient of
   -elbo with respect to every parameter.
@@ -87,10 +88,24 @@ def run_epoch_case(ec):
                                           dx_scale=case["dx_scale"], theta_prior=case["theta_prior"], augment_rotation=False,
                                           z_scale=zs, epoch=e, num_epochs=len(ec["z_scales"]), N=int(bounds[-1]), use_cuda=False)
             means.append([float(v) for v in acc])                       # (elbo_accum, gen/bce_loss_accum, kl_loss_accum)
+        # the evaluation pass of the same script over the same minibatches with the trained networks (eval_model:
+        # train_mnist.py:174-226, train_particles.py:205-245): forward only, its own noise draws
+        nsteps = len(steps)
+        with _Noise(inp["r_eval"]), torch.no_grad():
+            if case["script"] == "mnist":
+                ev = mod.eval_model(it, x, p_net, q_net, rotate=case["rotate"], translate=case["translate"],
+                                    dx_scale=case["dx_scale"], theta_prior=case["theta_prior"], use_cuda=False)
+            else:
+                ev = mod.eval_model(it, x, mask, p_net, q_net, rotate=case["rotate"], translate=case["translate"],
+                                    dx_scale=case["dx_scale"], theta_prior=case["theta_prior"], z_scale=ec["z_scales"][-1],
+                                    use_cuda=False)
+        eval_steps = steps[nsteps:]
+        del steps[nsteps:]
     finally:
         sys.stderr = stderr
         mod.eval_minibatch = orig_eval
-    out = {"steps": np.array(steps, np.float64), "means": np.array(means, np.float64)}
+    out = {"steps": np.array(steps, np.float64), "means": np.array(means, np.float64),
+           "eval_steps": np.array(eval_steps, np.float64), "eval_means": np.array([float(v) for v in ev], np.float64)}
     for k, p in p_net.named_parameters():
         out["p." + k] = p.detach().numpy()
     for k, p in q_net.named_parameters():

@@ -76,6 +76,14 @@ def test_run_epoch_matches_reference_train_epoch(name):
     for k, v in q_net.state_dict().items():
         assert rel_err(v.cpu().numpy(), gold["q." + k]) < TOL_PARAM, k
     assert step.aliased()
+    # the evaluation pass (eval_model: forward only, its own noise) over the same minibatches with the trained networks;
+    # the parameters agree with the reference's to 1e-4, so do the metrics
+    kw = {} if script == "mnist" else {"z_scale": ec["z_scales"][-1]}
+    noise = [torch.from_numpy(r).to(dev) for r in inp["r_eval"]]
+    ev = cli.run_epoch(script, step, x, batches, False, int(bounds[-1]), 0, 1, 0, 1, 0,
+                       dict(data=data, mask=mask, kw=kw, inf_dim=C.inf_dim(case), noise=noise))
+    assert np.abs(np.array(ev) - gold["eval_means"]).max() <= 1e-4 * np.abs(gold["eval_means"]).max(), (ev, gold["eval_means"])
+    assert not p_net.training and not q_net.training                       # eval_model leaves the networks in eval mode
 
 
 @pytest.mark.parametrize("name", [c["name"] for c in C.VANILLA_CASES])
