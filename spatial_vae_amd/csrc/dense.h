@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     wait_vm1<15 + P>(av[gl][e]);
-                    // rank-1 forms: act'(a) in ONE fma -- tanh 1 - a^2 (LASTD == 2), sigmoid a - a^2 (LASTD == 3)
+                    // rank-1 forms: act'(a) in ONE fma -- tanh 1 - a^2 (LASTD == 2), sigmoid a - a^2 (LASTD == 3).  (Forming it
+                    // one slot ahead, behind the previous MFMA group, was measured: no change -- the cost is the VALU
+                    // instruction's share of the matrix pipe, ~13 cycles per slot, not the dependency.)
                     const float x = LASTD == 1 ? sdo[e] * act_grad_rt(acoef, av[gl][e])
                                     : LASTD == 2 ? __builtin_fmaf(-av[gl][e], av[gl][e], 1.0f)
                                     : LASTD == 3 ? __builtin_fmaf(-av[gl][e], av[gl][e], av[gl][e])
@@ -749,6 +751,33 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             }
         }
     };
+    // R1: the same work in two phases, so that the LDS round trip of the next octet's fragments hides under this octet's
+    // 64 MFMAs (this kernel runs ONE wave per SIMD: whatever this wave waits for, the matrix pipe waits for too) and only the
+    // 32 VALU ops of the transform stand between two MFMA batches.
+    auto frag_raw = [&](long o, float4 (&xa)[4], float4 (&xb)[4], float4& d) {
+        const float* sl = ring + ((o - o0) & 3) * kSlotFloats + lane * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xa[t] = *reinterpret_cast<const float4*>(sl + t * 256);
+            xb[t] = *reinterpret_cast<const float4*>(sl + (4 + t) * 256);
+        }
+        d = *reinterpret_cast<const float4*>(ring + ((o - o0) & 3) * kSlotFloats + 8 * 256 + h * 4);
+    };
+    auto frag_post = [&](long o, float4 (&xa)[4], const float4& d) {
+        if (own_out) {  // dW_o / db_o partials from the raw a_{L-1} fragments (see frag)
+            const float wgt = (o < o1) ? 1.0f : 0.0f;
+            pbias[0] += wgt * ((d.x + d.y) + (d.z + d.w));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pw[0][t] += wgt * ((d.x * xa[t].x + d.y * xa[t].y) + (d.z * xa[t].z + d.w * xa[t].w));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // act'(a) d: t = d a, then tanh d - t a = d (1 - a^2), sigmoid t - t a = d a (1 - a)
+            const float4 v = xa[t];
+            const float4 tt = make_float4(d.x * v.x, d.y * v.y, d.z * v.z, d.w * v.w);
+            xa[t] = make_float4(__builtin_fmaf(-tt.x, v.x, R1 == 1 ? d.x : tt.x), __builtin_fmaf(-tt.y, v.y, R1 == 1 ? d.y : tt.y),
+                                __builtin_fmaf(-tt.z, v.z, R1 == 1 ? d.z : tt.z), __builtin_fmaf(-tt.w, v.w, R1 == 1 ? d.w : tt.w));
+        }
+    };
     auto mul = [&](const float4 (&xa)[4], const float4 (&xb)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -776,15 +805,23 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         dma(o0 + 2);
         if (CL > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        frag(o0, ca, cb);
+        float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (R1 != 0) {
+            frag_raw(o0, ca, cb, nd);
+            frag_post(o0, ca, nd);
+        } else {
+            frag(o0, ca, cb);
+        }
         for (long o = o0; o < o1; ++o) {
             dma(o + 3);
             if (CL > 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // DMA(o+1) has landed (9 pieces per octet)
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            frag(o + 1, na, nb);
-            if (CL == 0) __builtin_amdgcn_sched_barrier(0);
+            if (R1 != 0) frag_raw(o + 1, na, nb, nd);
+            else frag(o + 1, na, nb);
+            if (CL == 0 || R1 != 0) __builtin_amdgcn_sched_barrier(0);
             mul(ca, cb);
-            if (CL == 0) __builtin_amdgcn_sched_barrier(0);
+            if (CL == 0 || R1 != 0) __builtin_amdgcn_sched_barrier(0);
+            if (R1 != 0) frag_post(o + 1, na, nd);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 ca[t] = na[t];
