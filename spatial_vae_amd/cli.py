@@ -60,10 +60,10 @@ def activation_class(script, name):
     return nn.Tanh if name == "tanh" else nn.LeakyReLU
 
 
-def pick_device(d):
+def pick_device(d, world=1, local=0):
     """-d/--device: -1 = CPU, >= 0 = that GPU, -2 (default) = GPU if there is one (train_mnist.py:323-327).
-    The MI355X decoder has no CPU path, so a CPU request is refused up front."""
-    rank, world, local = dp.env_world()
+    The MI355X decoder has no CPU path, so a CPU request is refused up front.  Under data-parallel execution the
+    device is the rank's local one (dp.init_process_group: LOCAL_RANK, or 0 for every rank in the shared-GPU rehearsal)."""
     if d == -1 or not torch.cuda.is_available():
         raise SystemExit("spatial_vae_amd: the decoder runs on an MI355X only (-d -1 / no GPU is not supported)")
     idx = d if d >= 0 else local
@@ -221,8 +221,11 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
 def train_main(script, args, build):
     """`build(args, device)` returns dict(y_train, y_test, ctf_train, ctf_test, mask, n, m, channels,
     p_net, q_net, rotate, translate, table)."""
-    rank, world, _ = dp.init_process_group(device_is_gpu=True)
-    device = pick_device(args.device)
+    rank, world, local = dp.init_process_group(device_is_gpu=True)
+    device = pick_device(args.device, world, local)
+    if getattr(args, "seed", None) is not None:     # an addition: reproducible runs (weights, shuffle, noise, augmentation)
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed % (2 ** 32))
     if getattr(args, "gemm", None):                 # before the first decoder call: buffer sizes depend on the mode
         from . import _lib
         _lib.set_gemm_mode(args.gemm)

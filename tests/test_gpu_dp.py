@@ -138,3 +138,39 @@ def test_train_particles_saving_every_epoch_keeps_training(tmp_path):
         assert any(not torch.equal(a[k], b[k]) for k in a)
     rows = [l.split("\t") for l in out.stdout.splitlines() if "\ttrain\t" in l]
     assert float(rows[2][2]) > float(rows[0][2])                      # the training ELBO keeps improving
+
+
+def test_command_line_under_two_ranks_prints_the_single_rank_table(tmp_path):
+    """train_mnist.py end to end, one rank against two ranks sharing cuda:0, same --seed: the loop shards every GLOBAL
+    minibatch (ragged last one: 200 images in batches of 64 -> 64, 64, 64, 8), draws one noise tensor per global batch, and
+    all-reduces the metrics inside the gradient buckets -- so both runs print the same table (up to fp32 summation order)."""
+    import numpy as np
+    args = ["--synthetic", "200", "--num_epochs", "2", "--minibatch_size", "64", "--p_hidden_dim", "64", "--q_hidden_dim", "32",
+            "--progress_every", "0", "--save_interval", "100", "--seed", "11", "-l", "1e-3"]
+    script = os.path.join(ROOT, "train_mnist.py")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, script] + args + ["--save_prefix", "one"], cwd=str(tmp_path), env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-3000:]
+    env["SVAE_SHARE_GPU"] = "1"
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r] + %r))" % (ROOT, script, args + ["--save_prefix", "two"]))
+    two = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stdout[-1500:] + two.stderr[-3000:]
+
+    def table(out):
+        rows = [l.split("\t") for l in out.splitlines() if "\t" in l]
+        assert rows[0] == ["Epoch", "ELBO", "BCE loss", "KL"]
+        return np.array([[float(v) for v in r] for r in rows[1:]])
+
+    a, b = table(one.stdout), table(two.stdout)
+    assert a.shape == b.shape == (4, 4)                              # rank 0 alone prints, once per line
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), (a, b)
+    assert a[2, 1] > a[0, 1]                                         # and the model trained
+    import torch
+    p1 = torch.load(tmp_path / "outputs_one" / "trained" / "one_generator_epoch2.sav", weights_only=False).state_dict()
+    p2 = torch.load(tmp_path / "outputs_two" / "trained" / "two_generator_epoch2.sav", weights_only=False).state_dict()
+    for k in p1:
+        assert (p1[k] - p2[k]).abs().max().item() <= 1e-5 * max(p1[k].abs().max().item(), 1e-3), k

@@ -41,6 +41,8 @@ def galaxy_arguments(argv=None):
     p.add_argument("--invert_colours", action="store_true")
     p.add_argument("--synthetic", type=int, default=0, help="train on this many synthetic 32x32x3 images (paths ignored)")
     p.add_argument("--progress_every", type=int, default=50)
+    p.add_argument("--seed", type=int, default=None,
+                   help="seed torch and numpy before the networks are built (the reference has no such flag: unseeded by default)")
     p.add_argument("--gemm", choices=["fp32", "fp16x3"], default=None,
                    help="hidden-layer GEMM path (default: SVAE_GEMM or fp32 MFMA; fp16x3 = fp32-accurate split-operand f16 MFMA)")
     return p.parse_args(argv)

@@ -37,6 +37,8 @@ def mnist_arguments(argv=None):
     # additions
     p.add_argument("--synthetic", type=int, default=0, help="train on this many synthetic 28x28 images (no data files)")
     p.add_argument("--progress_every", type=int, default=50, help="stderr progress line every N steps (0 = never)")
+    p.add_argument("--seed", type=int, default=None,
+                   help="seed torch and numpy before the networks are built (the reference has no such flag: unseeded by default)")
     p.add_argument("--gemm", choices=["fp32", "fp16x3"], default=None,
                    help="hidden-layer GEMM path (default: SVAE_GEMM or fp32 MFMA; fp16x3 = fp32-accurate split-operand f16 MFMA)")
     return p.parse_args(argv)
