@@ -225,6 +225,25 @@ int svae_elbo_head_backward(const float* g_elbo, const float* g_logp, const floa
 int svae_colsum(const float* x, int32_t rows, int32_t cols, float* out, svae_stream_t stream);
 
 /*
+ * A Linear layer of the inference network with its activation, for the small row counts of the encoder (one row per image):
+ * replaces nn.Linear + activation() of InferenceNetwork.layers (spatial_vae/models.py:31-43, 46-54) and their autograd
+ * backward.  fp32 MFMA (v_mfma_f32_16x16x4_f32), one 16 x 16 output tile per wave, bias and activation in the epilogue.
+ *   forward : out[m][n] = act( sum_k x[m][k] weight[n][k] + bias[n] );  x (rows, in), weight (out, in) as nn.Linear keeps it,
+ *             bias (out) or NULL, out (rows, out);  act = SVAE_ACT_* or SVAE_LINEAR_ACT_NONE
+ *   backward: with dpre = dout * act'(out):  dweight (out, in) = dpre^T x,  dbias (out) = column sums of dpre,
+ *             dx (rows, in) = dpre weight -- any of the three may be NULL; ONE launch produces all that are asked for.
+ *             `out` is the forward's output (act' is taken through it); it may be NULL when act == SVAE_LINEAR_ACT_NONE.
+ * Meant for layers whose weights are a few MB; the first layer of the galaxy encoder (49 152 x 5 000) is a real GEMM and
+ * stays with the vendor library.
+ */
+#define SVAE_LINEAR_ACT_NONE (-1)
+int svae_linear_forward(const float* x, const float* weight, const float* bias, float* out, int32_t rows, int32_t in_features,
+                        int32_t out_features, int32_t act, svae_stream_t stream);
+int svae_linear_backward(const float* x, const float* weight, const float* out, const float* dout, int32_t rows,
+                         int32_t in_features, int32_t out_features, int32_t act, float* dweight, float* dbias, float* dx,
+                         svae_stream_t stream);
+
+/*
  * One Adam update over a flat fp32 parameter buffer: the arithmetic of torch.optim.Adam (amsgrad off, no weight
  * decay) as the reference uses it (optim = torch.optim.Adam(params, lr=lr); optim.step(), train_mnist.py:389,
  * 149), element-wise:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
@@ -288,7 +307,7 @@ int svae_gemm_mode_get(void);
  * number of launches, then clears the records.  Not for use under stream capture.  The reference
  * has no counterpart (it has no profiling at all: SURVEY.md section 5).
  */
-#define SVAE_PROF_KINDS 16
+#define SVAE_PROF_KINDS 20
 int svae_profile_enable(int on);
 int svae_profile_read(double* ms_total, int64_t* launches); /* arrays of SVAE_PROF_KINDS */
 const char* svae_profile_kind_name(int kind);

@@ -25,7 +25,7 @@ def _declared_symbols():
 
 
 EXPORTS = _declared_symbols()
-PROF_KINDS = 16
+PROF_KINDS = 20
 
 
 class Desc(ctypes.Structure):
@@ -99,6 +99,10 @@ def lib():
     L.svae_elbo_head_backward.argtypes = [vp, vp, vp, i32, vp, vp, vp]
     L.svae_colsum.restype = ctypes.c_int
     L.svae_colsum.argtypes = [vp, i32, i32, vp, vp]
+    L.svae_linear_forward.restype = ctypes.c_int
+    L.svae_linear_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.svae_linear_backward.restype = ctypes.c_int
+    L.svae_linear_backward.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.svae_adam_step.restype = ctypes.c_int
     L.svae_adam_step.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_int64, i32, vp]

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "dense.h"
 #include "elementwise.h"
+#include "encoder.h"
 #include "split.h"
 
 using namespace svae;
@@ -269,10 +270,11 @@ int check_ws(const Plan& p, const void* ws, size_t ws_bytes) {
 
 // ---- opt-in per-kernel timing with HIP events (svae_profile_*)
 enum Kind { K_PREPARE = 0, K_LAYER0_FWD, K_DENSE_FWD, K_OUT_FWD, K_DLOGITS, K_OUT_BWD, K_WGRAD, K_WGRAD_REDUCE,
-            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_ADAM, K_AUGMENT, K_COUNT };
+            K_DENSE_DGRAD, K_LAYER0_BWD, K_SMALL_BWD, K_BCE, K_GAUSSIAN, K_LATENT, K_ADAM, K_AUGMENT, K_ENCODER, K_COUNT };
 const char* const kKindNames[SVAE_PROF_KINDS] = {"prepare", "layer0_fwd", "dense_fwd", "out_fwd", "dlogits", "out_bwd",
                                                  "wgrad", "wgrad_reduce", "dense_dgrad", "layer0_bwd", "small_bwd", "bce",
-                                                 "gaussian", "latent", "adam", "augment"};
+                                                 "gaussian", "latent", "adam", "augment", "encoder", "", "", ""};
+static_assert(K_COUNT <= SVAE_PROF_KINDS, "svae_profile_read arrays too small");
 // which kernel family a call actually dispatched (svae_path_counts): the GEMM mode is a request, the plan decides per
 // geometry (fp16x3 falls back to the fp32 kernels for unbounded activations and odd tile counts), and a test must be able
 // to tell a run of the split kernels from a silent fallback
@@ -1092,6 +1094,41 @@ int svae_colsum(const float* x, int32_t rows, int32_t cols, float* out, svae_str
     Scope prof(K_SMALL_BWD, st);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 31) / 32)), dim3(256), 0, st, x, out, cols, cols, rows);
     return launch_status("svae_colsum");
+}
+
+int svae_linear_forward(const float* x, const float* weight, const float* bias, float* out, int32_t rows, int32_t in_features,
+                        int32_t out_features, int32_t act, svae_stream_t stream) {
+    if (!x || !weight || !out || rows < 1 || in_features < 1 || out_features < 1)
+        return fail(SVAE_E_INVALID, "svae_linear_forward: bad arguments");
+    if (act < SVAE_LINEAR_ACT_NONE || act > SVAE_ACT_SIGMOID) return fail(SVAE_E_INVALID, "svae_linear_forward: unknown activation %d", act);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_ENCODER, st);
+    LinFwdArgs a{x, weight, bias, out, rows, in_features, out_features, act};
+    const long tiles = (long)((rows + 15) / 16) * ((out_features + 15) / 16);   // one workgroup (4 waves) per 16 x 16 tile
+    const bool vec = in_features % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(weight)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(enc_linear_fwd_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(enc_linear_fwd_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+    return launch_status("svae_linear_forward");
+}
+
+int svae_linear_backward(const float* x, const float* weight, const float* out, const float* dout, int32_t rows,
+                         int32_t in_features, int32_t out_features, int32_t act, float* dweight, float* dbias, float* dx,
+                         svae_stream_t stream) {
+    if (!x || !weight || !dout || rows < 1 || in_features < 1 || out_features < 1)
+        return fail(SVAE_E_INVALID, "svae_linear_backward: bad arguments");
+    if (act < SVAE_LINEAR_ACT_NONE || act > SVAE_ACT_SIGMOID) return fail(SVAE_E_INVALID, "svae_linear_backward: unknown activation %d", act);
+    if (act != SVAE_LINEAR_ACT_NONE && !out) return fail(SVAE_E_INVALID, "svae_linear_backward: the layer's output is needed for act'");
+    if (!dweight && !dbias && !dx) return SVAE_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scope prof(K_ENCODER, st);
+    LinBwdArgs a{x, weight, out, dout, dweight, dbias, dx, rows, in_features, out_features, act, 0};
+    const long tk = (in_features + 15) / 16;
+    a.tiles_w = (dweight || dbias) ? (int)(((out_features + 15) / 16) * tk) : 0;
+    const long groups = a.tiles_w + (dx ? (long)((rows + 15) / 16) * tk : 0);   // one workgroup per tile of dW or dx
+    const bool vecx = out_features % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vecx) hipLaunchKernelGGL(enc_linear_bwd_kernel<true>, dim3((unsigned)groups), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(enc_linear_bwd_kernel<false>, dim3((unsigned)groups), dim3(256), 0, st, a);
+    return launch_status("svae_linear_backward");
 }
 
 int svae_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

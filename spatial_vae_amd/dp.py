@@ -107,9 +107,18 @@ class FlatGrads(object):
       .grad IS its view and autograd accumulates into it in place.
     """
 
+    ALIGN = 64   # elements: every parameter starts on a 256-byte boundary of the flat buffers (the kernels read weights with
+                 # 16-byte loads); the padding holds zeros in both buffers and stays zero under Adam
+
     def __init__(self, params, sink_params=None, flatten_params=False, tail=0):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.offsets = []
+        n = 0
+        for p in self.params:
+            n = (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.offsets.append(n)
+            n += p.numel()
+        n = (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         ref = self.params[0]
         self.n = n
         # `tail` extra floats after the gradients ride along in the same collective (TrainStep: the logged scalars)
@@ -121,9 +130,8 @@ class FlatGrads(object):
         self.sinks = {}
         self._sink_list = []
         if flatten_params:
-            self.flat_param = torch.empty(n, dtype=torch.float32, device=ref.device)
-        off = 0
-        for p in self.params:
+            self.flat_param = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        for p, off in zip(self.params, self.offsets):
             view = self.flat[off:off + p.numel()].view_as(p)
             if flatten_params:
                 pv = self.flat_param[off:off + p.numel()].view_as(p)
@@ -135,7 +143,6 @@ class FlatGrads(object):
                 p.grad = None
             else:
                 p.grad = view
-            off += p.numel()
 
     def zero(self, already_cleared=False):
         """optim.zero_grad(): clear the flat buffer (unless the optimiser kernel already did) and detach the sink
@@ -202,7 +209,8 @@ class TrainStep(object):
                     q_sinks["layers.%d.bias" % idx] = m.bias
             sink_params = dict(sink_params, **q_sinks)
         self.grads = FlatGrads(params, sink_params=sink_params, flatten_params=True, tail=3)
-        self.n_p = sum(p.numel() for p in p_params)      # [0, n_p) = the decoder's bucket
+        # [0, n_p) = the decoder's bucket: up to where the first encoder parameter starts
+        self.n_p = self.grads.offsets[len(p_params)] if len(p_params) < len(self.grads.params) else self.grads.n
         # static (never data dependent), so that every rank issues the same collectives in the same order
         self._bucketed = bool(sink_params) if bucketed is None else bool(bucketed)
         if sink_params:

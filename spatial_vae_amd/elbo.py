@@ -23,21 +23,49 @@ import torch.nn as nn
 from . import ops
 
 
+_ENC_ACT_NAMES = {nn.Tanh: "tanh", nn.LeakyReLU: "leakyrelu", nn.ReLU: "relu", nn.Sigmoid: "sigmoid"}
+
+
+def _fusable_act(m):
+    """Name of an activation module the small-batch Linear kernel can fold into its epilogue, else None."""
+    name = _ENC_ACT_NAMES.get(type(m))
+    if name == "leakyrelu" and m.negative_slope != 0.01:
+        return None
+    return name
+
+
 def _encode(q_net, y2d):
     """Raw encoder output [z_mu | z_logstd] (B, 2*inf_dim): InferenceNetwork.forward is layers(x) split in two
-    (models.py:46-54); any other encoder's two outputs are concatenated back."""
+    (models.py:46-54); any other encoder's two outputs are concatenated back.
+
+    On the device the plain Linear layers of InferenceNetwork.layers run through ops.enc_linear -- one launch per layer
+    forward (bias + activation in the epilogue) and one backward (dW, db, dx) -- with the gradient sinks of dp.TrainStep when
+    they are set (views into its flat buffer: no AccumulateGrad adds).  Layers the kernel does not cover (ResidLinear, weights
+    above 4 M elements such as the galaxy encoder's 49 152 x 5 000 first layer) stay torch ops (ops.sink_linear / the module)."""
     if hasattr(q_net, "layers") and hasattr(q_net, "latent_dim"):
-        sinks = getattr(q_net, "_grad_sinks", None)     # set by dp.TrainStep: gradient views into its flat buffer
-        if sinks and torch.is_grad_enabled():
-            h = y2d
-            for idx, m in enumerate(q_net.layers):
-                key = "layers.%d.weight" % idx
-                if isinstance(m, nn.Linear) and key in sinks:
-                    h = ops.sink_linear(h, m.weight, m.bias, sinks[key], sinks["layers.%d.bias" % idx])
-                else:
-                    h = m(h)
-            return h
-        return q_net.layers(y2d)
+        sinks = getattr(q_net, "_grad_sinks", None) or {}
+        sinks = sinks if torch.is_grad_enabled() else {}
+        if not y2d.is_cuda:
+            return q_net.layers(y2d)
+        mods = list(q_net.layers)
+        h = y2d
+        idx = 0
+        while idx < len(mods):
+            m = mods[idx]
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                sw, sb = sinks.get("layers.%d.weight" % idx), sinks.get("layers.%d.bias" % idx)
+                if ops.enc_linear_applies(h, m.weight):
+                    act = _fusable_act(mods[idx + 1]) if idx + 1 < len(mods) else None
+                    h = ops.enc_linear(h, m.weight, m.bias, act, sw, sb)
+                    idx += 2 if act is not None else 1
+                    continue
+                if sw is not None:
+                    h = ops.sink_linear(h, m.weight, m.bias, sw, sb)
+                    idx += 1
+                    continue
+            h = m(h)
+            idx += 1
+        return h
     z_mu, z_logstd = q_net(y2d)
     return torch.cat([z_mu, z_logstd], 1)
 

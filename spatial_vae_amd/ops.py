@@ -301,6 +301,61 @@ def elbo_head(loglik, kl_b):
     return _ElboHead.apply(loglik, kl_b)
 
 
+ENC_ACT = {None: -1, "tanh": 0, "leakyrelu": 1, "relu": 2, "sigmoid": 3}
+ENC_LINEAR_MAX_WEIGHT = 4 * 1024 * 1024     # elements: the hand-written layer is for weights of a few MB (see svae.h)
+
+
+def enc_linear_applies(x, weight):
+    """The small-batch Linear kernels take fp32 CUDA operands whose weight matrix has at most 4 M elements."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and
+            weight.numel() <= ENC_LINEAR_MAX_WEIGHT)
+
+
+class _EncLinear(torch.autograd.Function):
+    """out = act(x W^T + b) in ONE launch (svae_linear_forward); the backward pass is ONE launch too (svae_linear_backward):
+    dW, db and dx with act' applied to the upstream gradient as it is loaded.  Replaces an nn.Linear + activation pair of
+    InferenceNetwork.layers (models.py:31-43) -- addmm, tanh, tanh_backward, two mm and a column sum otherwise.  With sinks
+    (views of dp.FlatGrads' flat buffer) dW / db are written in place and not handed to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, sink_w, sink_b):
+        L = _lib.lib()
+        x, weight, bias = _f32(x), _f32(weight), _f32(bias)
+        rows, k = x.shape
+        n = weight.shape[0]
+        out = torch.empty(rows, n, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.svae_linear_forward(x.data_ptr(), weight.data_ptr(), _p(bias), out.data_ptr(), rows, k, n, ENC_ACT[act],
+                                             _stream(x.device)))
+        ctx.act = act
+        ctx.sinks = (sink_w, sink_b)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, weight, out = ctx.saved_tensors
+        sink_w, sink_b = ctx.sinks
+        dout = _f32(dout)
+        rows, k = x.shape
+        n = weight.shape[0]
+        want_x, want_w, want_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if want_x else None
+        dw = (sink_w if sink_w is not None else torch.empty_like(weight)) if want_w else None
+        db = (sink_b if sink_b is not None else torch.empty(n, dtype=torch.float32, device=x.device)) if want_b else None
+        with torch.cuda.device(x.device):
+            _lib.check(L.svae_linear_backward(x.data_ptr(), weight.data_ptr(), out.data_ptr(), dout.data_ptr(), rows, k, n,
+                                              ENC_ACT[ctx.act], _p(dw), _p(db), _p(dx), _stream(x.device)))
+        return (dx, None if (dw is None or dw is sink_w) else dw, None if (db is None or db is sink_b) else db, None, None, None)
+
+
+def enc_linear(x, weight, bias, act=None, sink_w=None, sink_b=None):
+    """act(x W^T + b), act in (None, "tanh", "leakyrelu", "relu", "sigmoid") -- see _EncLinear."""
+    return _EncLinear.apply(x, weight, bias, act, sink_w, sink_b)
+
+
 class _SinkLinear(torch.autograd.Function):
     """y = x W^T + b; the backward pass writes dW and db straight into caller-owned gradient views (slices of the flat
     buffer of dp.FlatGrads) with torch.mm(out=) / torch.sum(out=) instead of returning tensors that autograd would then

@@ -56,13 +56,15 @@ for y, r in zip(batches, noises):
 
 ref = torch.cat([p.detach().reshape(-1) for p in list(rp.parameters()) + list(rq.parameters())])
 mine = step.grads.flat_param
-err = (mine - ref).abs().max().item() / ref.abs().max().item()
+packed = torch.cat([mine[o:o + p.numel()] for p, o in zip(step.grads.params, step.grads.offsets)])   # without the alignment gaps
+err = (packed - ref).abs().max().item() / ref.abs().max().item()
 both = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(both, mine)
 assert torch.equal(both[0], both[1]), "replicas diverged"
 assert step.aliased()
 assert all(torch.equal(p.detach().reshape(-1), step.grads.flat_param[o:o + p.numel()]) for p, o in
-           zip(step.grads.params, [sum(q.numel() for q in step.grads.params[:i]) for i in range(len(step.grads.params))]))
+           zip(step.grads.params, step.grads.offsets))
+assert all(o % 64 == 0 for o in step.grads.offsets)
 print("rank", rank, "seed", seed, "param err", err)
 assert err < 1e-6, err
 dist.destroy_process_group()
