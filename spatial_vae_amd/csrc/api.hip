@@ -340,16 +340,27 @@ RowGeo row_geo(const Geo& g) {
     return r;
 }
 
-// tables + packed weights: needed by both directions, rebuilt per call (a few MB of traffic)
+// tables + packed weights, one launch (prepare_kernel): built by the forward call and carried to the backward call in `saved`
 void launch_prepare(const Geo& g, const Plan& pl, const svae_params* p, const PoseArgs& pa, const float* z, hipStream_t st) {
     Scope prof(K_PREPARE, st);
+    PrepareArgs a;
+    a.coord_w = p->coord_w; a.coord_b = p->coord_b;
+    a.latent_w = g.Zd > 0 ? p->latent_w : nullptr;
+    a.bil_w = (g.flags & SVAE_FLAG_BILINEAR) ? p->bilinear_w : nullptr;
+    a.z = z; a.tab = pl.tab; a.posebuf = pl.posebuf; a.pose = pa;
+    a.B = g.B; a.H = g.H; a.Hp = g.Hp; a.Zd = g.Zd; a.in_dim = g.in_dim;
     const long nt = (long)g.B * g.Hp;
-    hipLaunchKernelGGL(tables_kernel, dim3(blocks_for(nt > g.B ? nt : g.B)), dim3(256), 0, st, p->coord_w, p->coord_b,
-                       g.Zd > 0 ? p->latent_w : nullptr, (g.flags & SVAE_FLAG_BILINEAR) ? p->bilinear_w : nullptr, z,
-                       pl.tab, pl.posebuf, pa, g.B, g.H, g.Hp, g.Zd, g.in_dim);
-    for (int l = 0; l + 1 < g.L; ++l)
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks_for((long)g.Hp * g.Hp)), dim3(256), 0, st, p->hidden_w[l],
-                           pl.wf[l], pl.wb[l], g.H, g.Hp, (l == g.L - 2 && rank1_out(g)) ? p->out_w : (const float*)nullptr);
+    a.nb_tab = (int)blocks_for(nt > g.B ? nt : g.B);
+    a.nb_pack = (int)blocks_for((long)g.Hp * g.Hp);
+    a.nlayers = g.L - 1;
+    for (int l = 0; l < SVAE_MAX_HIDDEN; ++l) {
+        const bool on = l + 1 < g.L;
+        a.W[l] = on ? p->hidden_w[l] : nullptr;
+        a.wf[l] = on ? pl.wf[l] : nullptr;
+        a.wb[l] = on ? pl.wb[l] : nullptr;
+        a.wb_row_scale[l] = (on && l == g.L - 2 && rank1_out(g)) ? p->out_w : nullptr;
+    }
+    hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)(a.nb_tab + a.nb_pack * a.nlayers)), dim3(256), 0, st, a);
 }
 
 template <int NT, bool DGRAD, bool RESID, bool FIRST, int LASTD, int CF = 0>

@@ -34,7 +34,7 @@ namespace svae {
 // ------------------------------------------------------------------------------------------
 struct DenseArgs {
     const float* in;    // row operand, octet-major (Mp x Hp)
-    const float* wp;    // packed weights, 1 KiB slabs [Hp/8][Hp/32] of [k-quad 2][column 32][k 4] (pack_weights_kernel)
+    const float* wp;    // packed weights, 1 KiB slabs [Hp/8][Hp/32] of [k-quad 2][column 32][k 4] (prepare_kernel)
     float* out;         // octet-major (Mp x Hp)
     const float* bias;  // forward: (H) bias; data gradient: unused
     const float* aux;   // data gradient: a_{l-1} octet-major (its act' multiplies the result)

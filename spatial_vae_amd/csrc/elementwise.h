@@ -17,50 +17,58 @@ namespace svae {
 __device__ __forceinline__ long slab_index(int contr, int out, int ntile) {
     return (((long)(contr >> 3) * ntile + (out >> 5)) * 2 + ((contr >> 2) & 1)) * 128 + (out & 31) * 4 + (contr & 3);
 }
-// wb_row_scale (nullable): the data-gradient image holds W[n][k] * wb_row_scale[n] -- the rank-1 output-layer backward
-// (dense_kernel LASTD == 2) folds w_o[n] into the weights it contracts over n.
-__global__ void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ wf, float* __restrict__ wb, int H,
-                                    int Hp, const float* __restrict__ wb_row_scale) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)Hp * Hp) return;
-    const int n = idx / Hp, k = idx % Hp;
-    const float v = (n < H && k < H) ? W[(long)n * H + k] : 0.0f;
-    wf[slab_index(k, n, Hp / 32)] = v;
-    wb[slab_index(n, k, Hp / 32)] = (wb_row_scale && n < H) ? v * wb_row_scale[n] : v;
-}
-
 // ---------------------------------------------------------------- per-image tables
 // tab[b][k][0..4] = W_c[k][p] + sum_q W_bi[k][p][q] z[b][q]      (models.py:104, 114-121)
 // tab[b][k][5]    = b_c[k]   + sum_q W_z[k][q]  z[b][q]          (models.py:104, 111-112)
 // posebuf[b]      = (cos t_b, sin t_b, dx0, dx1)                  (train_mnist.py:54-58, 70-71)
-__global__ void tables_kernel(const float* __restrict__ coord_w, const float* __restrict__ coord_b,
-                              const float* __restrict__ latent_w, const float* __restrict__ bil_w,
-                              const float* __restrict__ z, float* __restrict__ tab, float4* __restrict__ posebuf,
-                              PoseArgs pose, int B, int H, int Hp, int Zd, int in_dim) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < B) {
-        float c, s, d0, d1;
-        image_pose(pose, (int)idx, c, s, d0, d1);
-        posebuf[idx] = make_float4(c, s, d0, d1);
-    }
-    if (idx >= (long)B * Hp) return;
-    const int b = idx / Hp, k = idx % Hp;
-    float out[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (k < H) {
-        for (int p = 0; p < in_dim; ++p) {
-            float w = coord_w[k * in_dim + p];
-            if (bil_w)
-                for (int q = 0; q < Zd; ++q) w += bil_w[((long)k * in_dim + p) * Zd + q] * z[(long)b * Zd + q];
-            out[p] = w;
+// wb_row_scale[l] (nullable): the data-gradient image of layer l holds W[n][k] * wb_row_scale[n] -- the rank-1 output-layer
+// backward (dense_kernel LASTD >= 2) folds w_o[n] into the weights it contracts over n.
+// Both in ONE launch (r01: one kernel for the tables and one per layer for the packing): what a forward call prepares from
+// the parameters, z and the pose.  Blocks [0, nb_tab) build the tables, the rest pack layer (blk - nb_tab) / nb_pack.
+struct PrepareArgs {
+    const float* coord_w; const float* coord_b; const float* latent_w; const float* bil_w; const float* z;
+    float* tab; float4* posebuf; PoseArgs pose;
+    int B, H, Hp, Zd, in_dim;
+    int nb_tab, nb_pack, nlayers;
+    const float* W[SVAE_MAX_HIDDEN]; float* wf[SVAE_MAX_HIDDEN]; float* wb[SVAE_MAX_HIDDEN];
+    const float* wb_row_scale[SVAE_MAX_HIDDEN];
+};
+__global__ void __launch_bounds__(256) prepare_kernel(PrepareArgs a) {
+    if ((int)blockIdx.x < a.nb_tab) {
+        const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+        if (idx < a.B) {
+            float c, s, d0, d1;
+            image_pose(a.pose, (int)idx, c, s, d0, d1);
+            a.posebuf[idx] = make_float4(c, s, d0, d1);
         }
-        float bias = coord_b[k];
-        if (latent_w)
-            for (int q = 0; q < Zd; ++q) bias += latent_w[(long)k * Zd + q] * z[(long)b * Zd + q];
-        out[kBiasSlot] = bias;
+        if (idx >= (long)a.B * a.Hp) return;
+        const int b = idx / a.Hp, k = idx % a.Hp;
+        float out[kSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k < a.H) {
+            for (int p = 0; p < a.in_dim; ++p) {
+                float w = a.coord_w[k * a.in_dim + p];
+                if (a.bil_w)
+                    for (int q = 0; q < a.Zd; ++q) w += a.bil_w[((long)k * a.in_dim + p) * a.Zd + q] * a.z[(long)b * a.Zd + q];
+                out[p] = w;
+            }
+            float bias = a.coord_b[k];
+            if (a.latent_w)
+                for (int q = 0; q < a.Zd; ++q) bias += a.latent_w[(long)k * a.Zd + q] * a.z[(long)b * a.Zd + q];
+            out[kBiasSlot] = bias;
+        }
+        float4* dst = reinterpret_cast<float4*>(a.tab + idx * kSlots);
+        dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+        dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+        return;
     }
-    float4* dst = reinterpret_cast<float4*>(tab + idx * kSlots);
-    dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-    dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+    const int rel = blockIdx.x - a.nb_tab;
+    const int l = rel / a.nb_pack;
+    const long idx = (long)(rel - l * a.nb_pack) * 256 + threadIdx.x;
+    if (l >= a.nlayers || idx >= (long)a.Hp * a.Hp) return;
+    const int n = idx / a.Hp, k = idx % a.Hp;
+    const float v = (n < a.H && k < a.H) ? a.W[l][(long)n * a.H + k] : 0.0f;
+    a.wf[l][slab_index(k, n, a.Hp / 32)] = v;
+    a.wb[l][slab_index(n, k, a.Hp / 32)] = (a.wb_row_scale[l] && n < a.H) ? v * a.wb_row_scale[l][n] : v;
 }
 
 struct RowGeo {

@@ -299,9 +299,14 @@ class TrainStep(object):
             elbo.backward(self._seed(weight))
             base = getattr(elbo, "_base", None)           # ops.elbo_head returns views of one (elbo, log_p, kl) vector
             vec = base if (base is not None and base.numel() == 3) else torch.stack([out[0], out[1], out[2]])
-            torch.mul(vec.detach(), float(weight), out=self.grads.tail)
+            if world_size() == 1 and weight == 1.0:
+                self.metrics = vec.detach()               # nothing to reduce: the minibatch's own metrics, no copy
+            else:
+                torch.mul(vec.detach(), float(weight), out=self.grads.tail)
+                self.metrics = self.grads.tail
         else:
             self.grads.tail.zero_()
+            self.metrics = self.grads.tail
         self._reduce()
         self.optim.step()
         self.grads.zero(already_cleared=getattr(self.optim, "zero_grad_in_step", False))
