@@ -3,11 +3,12 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 for d in sys.argv[1:]:
-    f = glob.glob(d + '/*/*_counter_collection.csv')[0]
-    t = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+    f = max(glob.glob(d + '/*/*_counter_collection.csv'), key=os.path.getmtime)
+    t = max(glob.glob(d + '/*/*_kernel_trace.csv'), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         agg[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))

@@ -6,6 +6,7 @@
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
@@ -28,7 +29,7 @@ def family(name):
 def main():
     d = sys.argv[1]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 20
-    f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+    f = max(glob.glob(d + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # the timed region = the last `steps` repetitions; a step ends with its (single) Adam launch

@@ -8,13 +8,14 @@ wide coalesced streaming reads by 2x, so corrected = (2*FETCH + WRITE) * 1024; f
 import collections
 import csv
 import glob
+import os
 import json
 import re
 import sys
 
 
 def per_kernel(d):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(d + "/*/*_counter_collection.csv"), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = re.sub(r"\(.*$", "", r["Kernel_Name"])
