@@ -226,6 +226,12 @@ def train_main(script, args, build):
     if getattr(args, "seed", None) is not None:     # an addition: reproducible runs (weights, shuffle, noise, augmentation)
         torch.manual_seed(args.seed)
         np.random.seed(args.seed % (2 ** 32))
+    # one seed for the whole job (rank 0's): the shuffle, the global noise draw and -- under DP -- everything drawn from
+    # np.random (the dataset shuffle of train_galaxy.py:372 inside build(), the augmentation angles) are then the same on
+    # every rank, which each slices [lo:hi)
+    seed = dp.shared_seed(device)
+    if world > 1:
+        np.random.seed(seed % (2 ** 32))
     if getattr(args, "gemm", None):                 # before the first decoder call: buffer sizes depend on the mode
         from . import _lib
         _lib.set_gemm_mode(args.gemm)
@@ -256,15 +262,12 @@ def train_main(script, args, build):
     mask = cfg.get("mask")
     mask = mask.to(device) if mask is not None else None
     N = tr["y"].size(0)
-    # one seed for the whole job (rank 0's): the shuffle, the global noise draw and -- under DP -- the augmentation
-    # angles are then the same on every rank, which each slices [lo:hi)
-    seed = dp.shared_seed(device)
+    if world > 1:       # every rank must hold the SAME resident dataset: the ranks slice one global minibatch by index
+        dp.assert_same_on_all_ranks(torch.stack([tr["y"].double().sum(), te["y"].double().sum()]), "the resident dataset")
     gen = torch.Generator()
     gen.manual_seed(seed)
     noise_gen = torch.Generator(device=device)
     noise_gen.manual_seed(seed)
-    if world > 1:
-        np.random.seed(seed % (2 ** 32))
     inf_dim = q_net.latent_dim
     out = sys.stdout
     header = cfg["table"]

@@ -175,6 +175,18 @@ def shared_seed(device):
     return seed
 
 
+def assert_same_on_all_ranks(t, what):
+    """Raise on every rank if the values of `t` (a small tensor) differ between ranks."""
+    if world_size() == 1:
+        return
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("data-parallel ranks disagree on %s (min %s, max %s): they must be identical replicas"
+                           % (what, lo.tolist(), hi.tolist()))
+
+
 class TrainStep(object):
     """forward + backward + (all-reduce) + Adam step for one (local) minibatch.
 

@@ -174,3 +174,25 @@ def test_command_line_under_two_ranks_prints_the_single_rank_table(tmp_path):
     p2 = torch.load(tmp_path / "outputs_two" / "trained" / "two_generator_epoch2.sav", weights_only=False).state_dict()
     for k in p1:
         assert (p1[k] - p2[k]).abs().max().item() <= 1e-5 * max(p1[k].abs().max().item(), 1e-3), k
+
+
+def test_unseeded_galaxy_run_under_two_ranks_holds_one_dataset(tmp_path):
+    """train_galaxy.py shuffles the training images with np.random inside build() (train_galaxy.py:372) and draws augmentation
+    angles from it; without --seed every process would shuffle differently and the ranks would slice DIFFERENT images out
+    of 'the same' global minibatch.  The loop seeds np.random from rank 0's seed before build() and checks the resident
+    dataset across ranks; the run must pass that check, train, and print one table."""
+    import numpy as np
+    args = ["x", "y", "--synthetic", "96", "--num_epochs", "2", "--minibatch_size", "32", "--p_hidden_dim", "32", "--q_hidden_dim",
+            "32", "--augment_rotation", "--save_prefix", "g2", "--progress_every", "0", "--save_interval", "100", "-l", "1e-3"]
+    script = os.path.join(ROOT, "train_galaxy.py")
+    env = dict(os.environ, PYTHONPATH=ROOT, SVAE_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r] + %r))" % (ROOT, script, args))
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    rows = [l.split("\t") for l in out.stdout.splitlines() if "\t" in l]
+    assert rows[0] == ["Epoch", "ELBO", "BCE loss", "KL"] and len(rows) == 5
+    vals = np.array([[float(v) for v in r] for r in rows[1:]])
+    assert np.isfinite(vals).all() and vals[2, 1] > vals[0, 1]
