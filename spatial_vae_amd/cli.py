@@ -28,20 +28,36 @@ from . import elbo as E
 
 
 class RunningMean(object):
-    """acc += b * (v - acc) / count  (train_mnist.py:156-164), kept on the device in float64.  `vec` is the
-    (elbo, log_p, kl) vector of one minibatch; the reference logs -log_p ("gen_loss"), and since negation commutes
-    with this arithmetic bit for bit, the sign is applied when the values are read."""
+    """acc += b * (v - acc) / count  (train_mnist.py:156-164) in Python doubles, exactly as the reference does it -- but
+    LAZILY: update() only keeps the minibatch's (elbo, log_p, kl) device vector, and values() fetches everything collected so far
+    in one transfer and replays the arithmetic on the host.  No kernel and no synchronisation per step (the reference pays
+    three .item() calls per step; a device-side accumulator paid five tiny kernels).  The reference logs -log_p ("gen_loss");
+    negation commutes with this arithmetic bit for bit, so the sign is applied when the values are read."""
 
-    def __init__(self, device, n=3):
-        self.acc = torch.zeros(n, dtype=torch.float64, device=device)
-        self.count = 0
+    def __init__(self, device=None, n=3):
+        self.acc = [0.0] * n
+        self.count = 0          # images whose metrics have been folded into acc
+        self.seen = 0           # images handed to update() so far
+        self.pending = []
 
-    def update(self, batch_size, vec):
-        self.count += batch_size
-        self.acc += batch_size * (vec.detach().double() - self.acc) / self.count
+    def update(self, batch_size, vec, volatile=False):
+        """vec: the minibatch's 3-vector on the device.  volatile=True: the tensor will be overwritten by the next step (the
+        data-parallel metric tail), so a copy is kept."""
+        self.seen += batch_size
+        self.pending.append((batch_size, vec.detach().clone() if volatile else vec.detach()))
+
+    def _flush(self):
+        if not self.pending:
+            return
+        host = torch.stack([v.reshape(-1) for _, v in self.pending]).cpu().double().tolist()   # the one synchronisation
+        for (b, _), row in zip(self.pending, host):
+            self.count += b
+            self.acc = [a + b * (v - a) / self.count for a, v in zip(self.acc, row)]
+        self.pending = []
 
     def values(self):
-        e, lp, k = (float(x) for x in self.acc.cpu())
+        self._flush()
+        e, lp, k = self.acc
         return [e, -lp, k]
 
 
@@ -189,7 +205,7 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
             if world > 1 and kw.get("augment_rotation") and step.eval_kwargs.get("rotate"):
                 kw["offset"] = E.draw_offsets(step.eval_kwargs["rotate"], gb)[lo:hi]   # np.random is seeded alike on all ranks
             out = step(x, *args, weight=(hi - lo) / gb, **kw)
-            mean.update(gb, step.metrics)
+            mean.update(gb, step.metrics, volatile=world > 1)
         else:
             vals = torch.zeros(3, device=x.device)
             if hi > lo:
@@ -207,7 +223,7 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
         if train and rank == 0 and progress_every > 0 and (it + 1) % progress_every == 0:
             e, g, k = mean.values()
             print("# [{}/{}] training {:.1%}, ELBO={:.5f}, Error={:.5f}, KL={:.5f}".format(
-                epoch + 1, num_epochs, mean.count / N, e, g, k), end="\r", file=sys.stderr)
+                epoch + 1, num_epochs, mean.seen / N, e, g, k), end="\r", file=sys.stderr)
     if pending:
         allv = torch.stack([v for _, v in pending])
         torch.distributed.all_reduce(allv)

@@ -71,7 +71,14 @@ def test_running_mean_matches_reference_arithmetic():
         ref = v * np.array([1.0, -1.0, 1.0])                                # the reference logs gen_loss = -log_p
         acc += b * (ref - acc) / count                                      # train_mnist.py:156-164
         rm.update(b, torch.tensor(v))                                       # (elbo, log_p, kl) as eval_minibatch returns them
+    assert rm.seen == sum(sizes) and rm.count == 0                          # nothing is computed (or synchronised) per step
     assert np.array_equal(np.array(rm.values()), acc)                       # bit for bit: negation commutes with the arithmetic
+    assert rm.count == sum(sizes) and not rm.pending
+    tail = torch.tensor([1.0, 2.0, 3.0])                                    # a buffer the next step overwrites (DP metric tail)
+    rm2 = RunningMean()
+    rm2.update(4, tail, volatile=True)
+    tail.zero_()
+    assert rm2.values() == [1.0, -2.0, 3.0]
 
 
 def test_coord_grid_matches_case_builder():
