@@ -301,8 +301,12 @@ def train_main(script, args, build):
         perm = torch.randperm(N, generator=gen)                      # DataLoader(shuffle=True): same order on every rank
         batches = [perm[i:i + bs].to(device) for i in range(0, N, bs)]
         train_kw = {"augment_rotation": True} if cfg.get("augment") and script != "mnist" else {}
+        t_epoch = time.time()
         e, g, k = run_epoch(script, step, x, batches, True, N, epoch, num_epochs, rank, world, args.progress_every,
                             dict(data=tr, mask=mask, kw=kw, train_kw=train_kw, inf_dim=inf_dim, noise_gen=noise_gen))
+        if rank == 0:       # run_epoch's values() synchronised: the epoch's training pass is complete
+            print("# epoch {}: {} training images in {:.3f} s = {:.0f} images/s".format(
+                epoch + 1, N, time.time() - t_epoch, N / max(time.time() - t_epoch, 1e-9)), file=sys.stderr)
         ntest = te["y"].size(0)
         order = torch.arange(ntest)
         tb = [order[i:i + bs].to(device) for i in range(0, ntest, bs)]
