@@ -25,7 +25,8 @@ The line also carries
   cpu_baseline : the torch-CPU restatement of the reference's step (oracle/torch_cpu_step.py) timed on this box's host
                  cores on a bounded sample of the same workload (rank 0, N=1 only): 2 warm-up steps, median of >= 5,
                  all usable cores, plus a 1-thread figure.
-  allreduce    : (N > 1) bytes per step and the time the compute stream spends waiting for the collectives.
+  allreduce    : (N > 1) bytes per step and the time the compute stream spends waiting for the collectives.  SVAE_DP_SOLO=1
+                 at N=1 issues the same collectives over a one-rank RCCL group: the per-step cost of the calls themselves.
   fp16x3_mode  : (config 2, N=1 only) the same workload measured in a child process with SVAE_GEMM=fp16x3 -- the hidden-layer
                  GEMMs on the f16 matrix pipe with split (hi + lo) operands, fp32-accurate.  Reported beside the headline,
                  which stays the fp32-MFMA path: `value`, `dtype` and `roofline` at the top level are that path's.
@@ -274,6 +275,11 @@ def main():
     from spatial_vae_amd import elbo as E
     _lib.set_gemm_mode(args.gemm)  # explicit (svae_gemm_mode_set); the environment variable covers child processes
 
+    # RCCL prints a version banner on stdout when a communicator is created; stdout carries exactly one JSON line, so file
+    # descriptor 1 points at stderr until the process group (and the first collective: TrainStep's broadcast) exist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local = dp.init_process_group(device_is_gpu=True)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -293,6 +299,12 @@ def main():
     fn = {"mnist": E.eval_minibatch_mnist, "galaxy": E.eval_minibatch_galaxy, "particles": E.eval_minibatch_particles}[cfg["script"]]
     step = dp.TrainStep(p_net, q_net, fn, lr=LR, fused_adam=True if args.graph else None, rotate=cfg["rotate"],
                         translate=cfg["translate"], dx_scale=DX_SCALE, theta_prior=cfg["theta_prior"])
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     x = torch.from_numpy(coord_grid(cfg["n"], cfg["n"])).to(dev)
     rs = np.random.RandomState(1000 + rank)
     npool = 4 if args.config != 4 else 2
@@ -311,7 +323,7 @@ def main():
 
     def run(k, timed=False):
         for i in range(k):  # each rank holds local_B of the global minibatch: its gradient enters the all-reduce with that weight
-            if timed and world > 1:
+            if timed and dp.collectives_on():
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 step.comm_events = pair
                 comm_pairs.append(pair)
@@ -385,7 +397,7 @@ def main():
                           "decoder_step_gflop_per_gpu": round(f_step / 1e9, 1),
                           "decoder_mfma_frac_of_step": round(f_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
                "roofline": roofline}
-        if world > 1:
+        if dp.collectives_on():     # N > 1, or the one-rank RCCL rehearsal (SVAE_DP_SOLO=1)
             nbytes = step.grads.buffer.numel() * 4
             out["allreduce"] = {"bytes_per_step": nbytes,
                                 "buckets_bytes": [step.n_p * 4, nbytes - step.n_p * 4] if step._bucketed else [nbytes],
@@ -398,7 +410,7 @@ def main():
         if world == 1 and not split and not args.no_secondary and args.config == 2:
             out["fp16x3_mode"] = secondary_mode(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

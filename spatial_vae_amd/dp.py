@@ -10,11 +10,13 @@ p_net, q_net and the Adam state; TrainStep broadcasts rank 0's parameters once a
 identical Adam update to identical gradients, so no further broadcast is needed.
 
 Every parameter's .grad is a view into one flat buffer, so the collective runs on the buffer the
-backward pass wrote -- no pack/unpack copies.  The buffer is laid out [p_net | q_net | 3 metrics]:
-the decoder's gradients are complete as soon as svae_decoder_backward has been enqueued, so their
-bucket is all-reduced on a side stream while autograd is still running the encoder's backward;
-the second bucket (q_net plus the three logged scalars elbo, log_p, kl, pre-weighted like the
-gradients) follows when backward() returns.  Two collectives per step, none for logging.
+backward pass wrote -- no pack/unpack copies.  The buffer is laid out [p_net | q_net | 3 metrics]
+(the three logged scalars elbo, log_p, kl, pre-weighted like the gradients: no collective for
+logging).  By default ONE all-reduce of the whole buffer follows backward().  With a heavy encoder
+(>= 32 M parameters: the galaxy configuration) the buffer goes out in two buckets: the decoder's
+gradients are complete as soon as svae_decoder_backward has been enqueued, so their bucket is
+all-reduced on a side stream while autograd is still running the encoder's backward, and the
+second bucket (q_net + metrics) follows when backward() returns.
 Backend: "nccl" (= RCCL on ROCm) when the parameters live on a GPU, "gloo" on CPU (tests) and
 for the shared-GPU rehearsal (SVAE_SHARE_GPU=1: every rank on cuda:0).
 """
@@ -47,7 +49,29 @@ def init_process_group(device_is_gpu):
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend="gloo")
+    elif world == 1 and solo_collectives() and device_is_gpu and not dist.is_initialized():
+        # SVAE_DP_SOLO=1: a ONE-rank RCCL group whose collectives are really issued (see collectives_on)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
     return rank, world, local
+
+
+def solo_collectives():
+    """SVAE_DP_SOLO=1: run the data-parallel code path -- parameter broadcast, the bucketed all-reduces on the side and compute
+    streams, the metric tail -- with a process group of ONE rank.  On a 1-GPU box this is the only way to execute the RCCL
+    transport calls themselves (backend "nccl"); the results must equal the plain single-process run."""
+    return os.environ.get("SVAE_DP_SOLO") == "1"
+
+
+def collectives_on():
+    """True when the step must issue its collectives: more than one rank, or the one-rank rehearsal."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or solo_collectives())
 
 
 def launch_ranks(nproc, argv, env=None, poll=0.2):
@@ -168,7 +192,7 @@ def shared_seed(device):
     """Rank 0's torch.initial_seed(), the same integer on every rank: seeds the shuffle permutation, the global noise
     draw and (under DP) the augmentation angles, so that every rank slices the SAME global minibatch."""
     seed = torch.initial_seed() % (2 ** 62)
-    if world_size() > 1:
+    if collectives_on():
         t = torch.tensor([seed], dtype=torch.int64, device=device)
         dist.broadcast(t, src=0)
         seed = int(t.item())
@@ -177,7 +201,7 @@ def shared_seed(device):
 
 def assert_same_on_all_ranks(t, what):
     """Raise on every rank if the values of `t` (a small tensor) differ between ranks."""
-    if world_size() == 1:
+    if not collectives_on():
         return
     lo, hi = t.clone(), t.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -224,7 +248,15 @@ class TrainStep(object):
         # [0, n_p) = the decoder's bucket: up to where the first encoder parameter starts
         self.n_p = self.grads.offsets[len(p_params)] if len(p_params) < len(self.grads.params) else self.grads.n
         # static (never data dependent), so that every rank issues the same collectives in the same order
-        self._bucketed = bool(sink_params) if bucketed is None else bool(bucketed)
+        if bucketed is None:
+            # Two buckets pay a cross-stream fork/join (measured on a one-rank RCCL group at BASELINE cfg 2: +0.080 ms per step
+            # against +0.045 ms for ONE all-reduce after backward()), which only an encoder backward long enough to hide the
+            # decoder bucket's transfer can repay: the galaxy encoder (271 M parameters, ~1 ms of GEMMs) yes, the 0.04 ms
+            # encoders of the other configs no.  SVAE_DP_BUCKETS=1|2 overrides the rule.
+            env = os.environ.get("SVAE_DP_BUCKETS")
+            n_q = sum(p.numel() for p in q_net.parameters())
+            bucketed = bool(sink_params) and (env == "2" or (env != "1" and n_q >= 32 * 1024 * 1024))
+        self._bucketed = bool(bucketed)
         if sink_params:
             p_net._grad_sinks = {k: v for k, v in self.grads.sinks.items() if k not in q_sinks}
             p_net._grad_sinks["__ready__"] = self._decoder_grads_ready
@@ -249,7 +281,7 @@ class TrainStep(object):
 
     def sync_replicas(self):
         """Make every replica rank 0's: each process initialised its modules from its own RNG."""
-        if world_size() > 1:
+        if collectives_on():
             dist.broadcast(self.grads.flat_param, src=0)
 
     def aliased(self):
@@ -263,7 +295,7 @@ class TrainStep(object):
     def _decoder_grads_ready(self):
         """Called by ops._Decoder.backward once svae_decoder_backward is enqueued: every p_net gradient is final, so its
         bucket goes out now, on a side stream, under the encoder's backward."""
-        if world_size() > 1 and self._bucketed and self._work_p is None:
+        if collectives_on() and self._bucketed and self._work_p is None:
             self._work_p = self._launch(self.grads.buffer[:self.n_p], side=True)
 
     def _launch(self, tensor, side):
@@ -274,7 +306,7 @@ class TrainStep(object):
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
 
     def _reduce(self):
-        if world_size() == 1:
+        if not collectives_on():
             return
         ev = self.comm_events
         if self._bucketed:
@@ -311,7 +343,7 @@ class TrainStep(object):
             elbo.backward(self._seed(weight))
             base = getattr(elbo, "_base", None)           # ops.elbo_head returns views of one (elbo, log_p, kl) vector
             vec = base if (base is not None and base.numel() == 3) else torch.stack([out[0], out[1], out[2]])
-            if world_size() == 1 and weight == 1.0:
+            if not collectives_on() and weight == 1.0:
                 self.metrics = vec.detach()               # nothing to reduce: the minibatch's own metrics, no copy
             else:
                 torch.mul(vec.detach(), float(weight), out=self.grads.tail)

@@ -28,9 +28,10 @@ torch.manual_seed(100 + rank)                       # every rank initialises dif
 with contextlib.redirect_stdout(io.StringIO()):
     p_net = models.SpatialGenerator(2, 64, num_layers=2, activation=nn.Tanh).to(dev)
     q_net = models.InferenceNetwork(n * m, 5, 32, num_layers=2, activation=nn.Tanh).to(dev)
-step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=1e-2, rotate=True, translate=True, dx_scale=0.1,
-                    theta_prior=math.pi / 4)
-assert step._bucketed and step.aliased()
+bucketed = os.environ.get("SVAE_TEST_BUCKETED") == "1"
+step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=1e-2, bucketed=bucketed if world > 1 else None, rotate=True,
+                    translate=True, dx_scale=0.1, theta_prior=math.pi / 4)
+assert step._bucketed == (bucketed and world > 1) and step.aliased()      # small encoder: one bucket unless asked otherwise
 seed = dp.shared_seed(dev)
 x = cli.coord_grid(n, m).to(dev)
 rs = np.random.RandomState(7)
@@ -68,11 +69,15 @@ else:
 '''
 
 
-def test_two_ranks_on_one_gpu_match_the_single_rank_run(tmp_path):
+@pytest.mark.parametrize("bucketed", [False, True], ids=["one_bucket", "two_buckets"])
+def test_two_ranks_on_one_gpu_match_the_single_rank_run(tmp_path, bucketed):
+    """Both collective schemes: ONE all-reduce after backward() (the default for small encoders) and the two-bucket form whose
+    first all-reduce is launched from inside backward() on a side stream (the default for the galaxy encoder)."""
     script = tmp_path / "dp_gpu_worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, SVAE_ROOT=ROOT, SVAE_DP_REF=str(tmp_path / "ref.pt"), PYTHONPATH=ROOT)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU"):
+    env = dict(os.environ, SVAE_ROOT=ROOT, SVAE_DP_REF=str(tmp_path / "ref.pt"), PYTHONPATH=ROOT,
+               SVAE_TEST_BUCKETED="1" if bucketed else "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU", "SVAE_DP_BUCKETS"):
         env.pop(k, None)
     one = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-3000:]
@@ -196,3 +201,59 @@ def test_unseeded_galaxy_run_under_two_ranks_holds_one_dataset(tmp_path):
     assert rows[0] == ["Epoch", "ELBO", "BCE loss", "KL"] and len(rows) == 5
     vals = np.array([[float(v) for v in r] for r in rows[1:]])
     assert np.isfinite(vals).all() and vals[2, 1] > vals[0, 1]
+
+
+_SOLO_WORKER = r'''
+import contextlib, io, math, os, sys
+sys.path.insert(0, os.environ["SVAE_ROOT"])
+import numpy as np, torch, torch.nn as nn, torch.distributed as dist
+import spatial_vae.models as models
+from spatial_vae_amd import dp, elbo as E, cli
+rank, world, local = dp.init_process_group(device_is_gpu=True)
+dev = torch.device("cuda", local)
+torch.manual_seed(5)
+with contextlib.redirect_stdout(io.StringIO()):
+    p_net = models.SpatialGenerator(2, 64, num_layers=2, activation=nn.Tanh).to(dev)
+    q_net = models.InferenceNetwork(144, 5, 32, num_layers=2, activation=nn.Tanh).to(dev)
+step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=1e-2, rotate=True, translate=True, dx_scale=0.1,
+                    theta_prior=math.pi / 4)
+x = cli.coord_grid(12, 12).to(dev)
+rs = np.random.RandomState(3)
+mets = []
+for i in range(4):
+    y = torch.from_numpy(rs.uniform(size=(8, 144)).astype(np.float32)).to(dev)
+    r = torch.from_numpy(rs.normal(size=(8, 5)).astype(np.float32)).to(dev)
+    step(x, y, noise=r)
+    mets.append(step.metrics.clone())
+torch.cuda.synchronize()
+print("backend", dist.get_backend() if dist.is_initialized() else "none", "collectives", dp.collectives_on())
+torch.save({"flat": step.grads.flat_param.detach().cpu(), "metrics": torch.stack(mets).cpu()}, os.environ["SVAE_OUT"])
+if dist.is_initialized():
+    dist.destroy_process_group()
+'''
+
+
+def test_one_rank_rccl_group_executes_the_collectives_and_changes_nothing(tmp_path):
+    """SVAE_DP_SOLO=1 runs the data-parallel step over a ONE-rank process group with backend "nccl" (= RCCL): the parameter
+    broadcast, the decoder bucket's all-reduce launched from inside backward() on the side stream, the second bucket with the
+    metric tail on the compute stream and the stream-level waits all execute on the real transport -- which a 1-GPU box
+    cannot otherwise reach -- and the trained parameters and metrics must be bit-identical to the plain run."""
+    import torch
+    script = tmp_path / "solo_worker.py"
+    script.write_text(_SOLO_WORKER)
+    outs = {}
+    for mode in ("plain", "solo", "solo2"):
+        env = dict(os.environ, SVAE_ROOT=ROOT, PYTHONPATH=ROOT, SVAE_OUT=str(tmp_path / (mode + ".pt")))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU", "SVAE_DP_SOLO", "SVAE_DP_BUCKETS"):
+            env.pop(k, None)
+        if mode != "plain":
+            env["SVAE_DP_SOLO"] = "1"
+            env["SVAE_DP_BUCKETS"] = "2" if mode == "solo2" else "1"
+        res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+        outs[mode] = (res.stdout, torch.load(tmp_path / (mode + ".pt"), weights_only=True))
+    assert "backend none collectives False" in outs["plain"][0]
+    for mode in ("solo", "solo2"):      # one all-reduce after backward / two buckets with the side-stream launch
+        assert "backend nccl collectives True" in outs[mode][0]
+        a, b = outs["plain"][1], outs[mode][1]
+        assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["metrics"], b["metrics"]), mode
