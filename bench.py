@@ -14,7 +14,7 @@ before the timed region.  Rank 0 prints ONE JSON line.
 and exits with their status; launched under torch.distributed.run it is one of the ranks.  --scaling weak (default): the
 config's batch PER GPU (global batch = N x batch); --scaling strong: the config's batch is the GLOBAL minibatch, sharded
 contiguously over the ranks.  Either way each rank's gradient enters the all-reduce weighted by
-local/global rows (spatial_vae_amd/dp.py: two buckets, the decoder's on a side stream under the encoder's backward).
+local/global rows (spatial_vae_amd/dp.py: one all-reduce per step; two buckets, the decoder's on a side stream, for heavy encoders).
 
 The line also carries
   roofline     : the dominant kernel (an fp32-MFMA GEMM of a decoder hidden layer) -- algorithmic FLOPs per launch / its
