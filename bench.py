@@ -382,6 +382,8 @@ def main():
                         "traffic_profile": traffic_profile,
                         "avg_launch_ms": round(avg_ms, 4), "flops_per_launch": f_gemm * (3 if split else 1),
                         "gemm_kernels_avg_ms": {k: round(v[0] / v[1], 4) for k, v in sorted(gemm.items())},
+                        "gemm_kernels_frac": {k: round(f_gemm * (3 if split else 1) / (v[0] / v[1] * 1e-3) / 1e12 / peak, 4)
+                                              for k, v in sorted(gemm.items())},
                         "kernels_ms_per_step": breakdown}
             if split:
                 roofline["note"] = ("executed f16 FLOPs (3 per algorithmic FLOP: hi*hi + hi*lo + lo*hi) against the f16 "
