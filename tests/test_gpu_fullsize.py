@@ -144,3 +144,42 @@ def test_decoder_backward_is_linear_in_upstream_gradient():
     a, b, ab = grads(g1), grads(g2), grads(2.0 * g1 - 3.0 * g2)
     for u, v, w in zip(a, b, ab):
         assert rel_err((2.0 * u - 3.0 * v).cpu().numpy(), w.cpu().numpy()) < 2e-5
+
+
+def test_bench_workload_tracks_the_cpu_port_over_adam_steps():
+    """The benchmark's own workload (bench.py: BASELINE cfg 2 at batch 256, default-initialised networks, lr 1e-4) stepped three
+    times through dp.TrainStep on the GPU and through the torch-CPU port of the reference step (oracle/torch_cpu_step.py, the
+    `cpu_baseline`) on the same targets and noise: the ELBO of every step and every parameter after the third Adam update must
+    agree -- what is timed is the computation the baseline times."""
+    import bench
+    from oracle import torch_cpu_step as T
+    from spatial_vae_amd import dp, elbo as E
+    cfg = dict(bench.CONFIGS[2])
+    dev = torch.device("cuda:0")
+    p_net, q_net = bench.build_nets(cfg)
+    p_state = {k: v.detach().clone().numpy() for k, v in p_net.state_dict().items()}
+    q_state = {k: v.detach().clone().numpy() for k, v in q_net.state_dict().items()}
+    grid = bench.coord_grid(cfg["n"], cfg["n"])
+    rs = np.random.RandomState(5)
+    ys = [torch.from_numpy(bench.synthetic_targets(cfg, rs, cfg["B"])) for _ in range(3)]
+    noise = [torch.from_numpy(rs.normal(size=(cfg["B"], bench.inf_dim(cfg))).astype(np.float32)) for _ in range(3)]
+    lr = 1e-3      # larger than the bench's 1e-4 so that three updates move the parameters well above fp32 noise
+    cpu = T.CpuTrainer(p_state, q_state, grid, lr=lr, script="mnist", act="tanh", rotate=True, translate=True,
+                       dx_scale=bench.DX_SCALE, theta_prior=cfg["theta_prior"])
+    p_net.to(dev)
+    q_net.to(dev)
+    step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=lr, rotate=True, translate=True, dx_scale=bench.DX_SCALE,
+                        theta_prior=cfg["theta_prior"])
+    x = torch.from_numpy(grid).to(dev)
+    for y, r in zip(ys, noise):
+        want = [float(v) for v in cpu.step(y, r)]
+        step(x, y.to(dev), noise=r.to(dev))
+        got = step.metrics.detach().cpu().numpy()
+        assert np.abs(got - np.array(want)).max() <= 2e-5 * np.abs(want).max(), (got, want)
+    moved = 0.0
+    for k, v in p_net.state_dict().items():
+        assert rel_err(v.cpu().numpy(), cpu.pp[k].detach().numpy()) < 1e-4, k
+        moved = max(moved, float(np.abs(v.cpu().numpy() - p_state[k]).max()))
+    for k, v in q_net.state_dict().items():
+        assert rel_err(v.cpu().numpy(), cpu.qp[k].detach().numpy()) < 1e-4, k
+    assert moved > 1e-3
