@@ -47,3 +47,16 @@ def test_single_gpu_line_carries_roofline_and_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread"]["value"] > 0
     assert "median" in c["sample"] and "2 warm-ups" in c["sample"]
+
+
+@pytest.mark.parametrize("config,batch,kernel_min_frac", [(3, 512, 0.5), (4, 128, 0.6), (5, 256, 0.5)])
+def test_every_baseline_config_has_a_bench_line(config, batch, kernel_min_frac):
+    """`bench.py --config N` runs BASELINE configs 3 (fit-noise particles), 4 (galaxy RGB, three hidden layers, the 271 M
+    parameter encoder that stays with the vendor GEMM) and 5 (particles with CTF filters built on the device) at their full
+    sizes and reports the dominant GEMM against the fp32-MFMA peak."""
+    d = _bench(["--config", str(config), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"])
+    assert d["config"]["baseline_config"] == config and d["config"]["global_batch"] == batch
+    assert d["value"] > 0 and d["dtype"] == "f32"
+    r = d["roofline"]
+    assert r["kernel"] in ("dense_fwd", "dense_dgrad", "wgrad") and kernel_min_frac < r["frac"] < 1.0
+    assert set(r["gemm_kernels_frac"]) == {"dense_fwd", "dense_dgrad", "wgrad"}
