@@ -114,3 +114,22 @@ def test_gemm_flag_selects_the_split_operand_path(tmp_path):
         assert all(np.isfinite(r).all() for r in v)
         assert v[2][1] > v[0][1]                                      # training ELBO improves epoch 0 -> 1
         assert -1000.0 < v[2][1] < -100.0                             # and sits where this tiny run always lands
+
+
+def test_train_particles_with_large_boxes_and_ctf(tmp_path):
+    """96 x 96 particles with CTF correction: the 95 x 95 filters are beyond the in-LDS limit of svae_ctf_filter (r01 aborted
+    at start-up there; the reference's ctf.py has no size limit) and beyond the LDS form of the fused CTF + Gaussian kernel, so
+    both take their global-memory forms.  One epoch must run and report finite numbers."""
+    from spatial_vae_amd import mrc
+    rs = np.random.RandomState(2)
+    for name, count in (("tr.mrcs", 24), ("te.mrcs", 8)):
+        with open(tmp_path / name, "wb") as f:
+            mrc.write(f, rs.normal(size=(count, 96, 96)).astype(np.float32))
+    tab = np.stack([rs.uniform(1, 3, 24), np.full(24, 2.7), np.full(24, 300.0), np.full(24, 1.7), np.full(24, 100.0),
+                    np.full(24, 10.0), np.zeros(24), rs.uniform(0, 180, 24)], 1)
+    np.savetxt(tmp_path / "ctf_tr.txt", tab)
+    np.savetxt(tmp_path / "ctf_te.txt", tab[:8])
+    rows = _run("train_particles.py", ["tr.mrcs", "te.mrcs", "--num-epochs", "1", "--minibatch-size", "8", "--p-hidden-dim", "32",
+                                       "--q-hidden-dim", "32", "--ctf-train", "ctf_tr.txt", "--ctf-test", "ctf_te.txt",
+                                       "--progress-every", "0"], str(tmp_path))
+    assert len(rows) == 3 and all(np.isfinite([float(v) for v in r.split("\t")[2:]]).all() for r in rows[1:])
