@@ -8,7 +8,7 @@ flag names and defaults, the step order (loss = -elbo; backward; step; zero_grad
 arithmetic, the stdout tables, train.txt / val.txt / command.txt / models.txt, and the whole-module
 `.sav` checkpoints with the reference's file names.  Dropped (out of scope): the
 interactive "clear outputs?" prompt (the run directory is created, never wiped), the loss-curve SVG, the zip
-archive, dataset download and MRC input (raises).  `--augment_rotation` runs on the device
+archive and dataset download.  `--augment_rotation` runs on the device
 (ops.rotate_augment, bit-identical to the reference's per-image Pillow loop).  Added: `--synthetic N`
 (train on N synthetic images when no data files exist), data-parallel execution under torchrun, and
 `--progress_every` (the reference pays three .item() syncs per step for its progress line).
@@ -65,6 +65,61 @@ def coord_grid(n_rows, n_cols):
     """(N, 2) grid of train_mnist.py:315-320."""
     x0, x1 = np.meshgrid(np.linspace(-1, 1, n_cols), np.linspace(1, -1, n_rows))
     return torch.from_numpy(np.stack([x0.ravel(), x1.ravel()], 1)).float()
+
+
+def loader_order(n, shuffle):
+    """Index order of one pass over torch.utils.data.DataLoader(dataset, batch_size, shuffle=shuffle) as the reference makes it
+    (train_mnist.py:395-396, :138, :196), consuming torch's global CPU generator the way iter(DataLoader) does: the iterator
+    draws one int64 (its worker base seed) whether or not the loader shuffles; RandomSampler then draws a second int64, seeds a
+    private generator with it and takes torch.randperm(n) from that one."""
+    torch.empty((), dtype=torch.int64).random_()
+    if not shuffle:
+        return torch.arange(n)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.randperm(n, generator=g)
+
+
+def pass_noise(sizes, inf_dim, device, after_first=()):
+    """The N(0,1) draws of one pass over minibatches of `sizes` images, from torch's global CPU generator in the reference's
+    order and shapes: one x.data.new(B, inf_dim).normal_() per minibatch (train_mnist.py:38; CPU tensors in the CPU reference),
+    and -- on a pass that dumps images -- the display helpers' draws right after the first minibatch's (`after_first`: their
+    shapes; train_mnist.py:107, train_galaxy.py:146, :177).  The shapes matter: the CPU normal_ kernel fills in blocks of 16 and
+    re-draws the tail, so one big draw is not the concatenation of the small ones.  Returns (per-minibatch device tensors,
+    display draws on the device); everything is uploaded in ONE transfer, nothing is drawn or copied inside the step loop."""
+    draws, extra = [], []
+    for i, b in enumerate(sizes):
+        draws.append(torch.empty(b, inf_dim).normal_())
+        if i == 0:
+            extra = [torch.empty(*shape).normal_() for shape in after_first]
+    flat = torch.cat([t.reshape(-1) for t in draws + extra]) if draws else torch.empty(0)
+    flat = flat.to(device, non_blocking=True)
+    out, off = [], 0
+    for t in draws + extra:
+        out.append(flat[off:off + t.numel()].view(t.shape))
+        off += t.numel()
+    return out[:len(draws)], out[len(draws):]
+
+
+def train_pass_plan(N, bs, inf_dim, device, home=None):
+    """(index minibatches, their noise) of one training pass: iter(DataLoader(shuffle=True)) then one draw per minibatch
+    (train_mnist.py:138-143 via :38).  The last minibatch is ragged, as the reference's loader keeps it (no drop_last)."""
+    perm = loader_order(N, True)
+    batches = [perm[i:i + bs].to(home if home is not None else device) for i in range(0, N, bs)]
+    noise, _ = pass_noise([b.numel() for b in batches], inf_dim, device)
+    return batches, noise
+
+
+def eval_pass_plan(ntest, bs, inf_dim, device, home=None, display_shapes=()):
+    """(index minibatches, their noise, the display helpers' noise) of one evaluation pass over the un-shuffled validation
+    loader (train_mnist.py:196-201); on a dump epoch eval_model decodes the first minibatch again for the PNG files
+    (train_mnist.py:214-224, train_galaxy.py:275-292) -- `display_shapes` maps a minibatch size to those draws' shapes."""
+    order = loader_order(ntest, False)
+    tb = [order[i:i + bs].to(home if home is not None else device) for i in range(0, ntest, bs)]
+    shapes = display_shapes(tb[0].numel()) if (display_shapes and tb) else ()
+    noise, shown = pass_noise([b.numel() for b in tb], inf_dim, device, after_first=shapes)
+    return tb, noise, shown
 
 
 def activation_class(script, name):
@@ -165,6 +220,15 @@ def _metric_vector(out):
     return torch.stack([out[0].detach(), out[1].detach(), out[2].detach()])
 
 
+def _take(t, sel, device):
+    """Rows `sel` of a dataset tensor on `device`: a gather in HBM when the dataset is resident there (the default, as the
+    reference preloads: train_mnist.py:329-332), a host gather + one asynchronous upload under --no-preload."""
+    if t.device == device:
+        return t[sel.to(device)]
+    rows = t[sel.cpu()]
+    return (rows.pin_memory() if device.type == "cuda" else rows).to(device, non_blocking=True)
+
+
 def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world, progress_every, extra):
     """One pass over `batches` (a list of index tensors into the resident data; every rank holds the same list).
     Training uses dp.TrainStep (forward, backward, all-reduce, Adam); evaluation only the forward (it is stochastic in
@@ -188,16 +252,16 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
         gb = idx.numel()
         lo, hi = dp.shard_bounds(gb, rank, world)
         sel = idx[lo:hi]
-        y = data["y"][sel]
+        y = _take(data["y"], sel, x.device)
         args = (y,)
         if script == "particles":
-            ctf = data["ctf"][sel] if data.get("ctf") is not None else None
+            ctf = _take(data["ctf"], sel, x.device) if data.get("ctf") is not None else None
             args = (y, extra.get("mask"), ctf)
         kw = dict(extra.get("kw", {}))
         if noise_list is not None:
             r = noise_list[it]
-        else:
-            r = torch.empty(gb, inf_dim, device=x.device, dtype=torch.float32).normal_(generator=extra["noise_gen"])
+        else:       # no prepared draws: the reference's per-minibatch draw from the global CPU generator (train_mnist.py:38)
+            r = torch.empty(gb, inf_dim).normal_().to(x.device, non_blocking=True)
         kw["noise"] = r[lo:hi]
         out = None
         if train:
@@ -205,7 +269,9 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
             if world > 1 and kw.get("augment_rotation") and step.eval_kwargs.get("rotate"):
                 kw["offset"] = E.draw_offsets(step.eval_kwargs["rotate"], gb)[lo:hi]   # np.random is seeded alike on all ranks
             out = step(x, *args, weight=(hi - lo) / gb, **kw)
-            mean.update(gb, step.metrics, volatile=world > 1)
+            # the data-parallel metric tail (also the one-rank RCCL rehearsal, and any weight != 1) is overwritten by the
+            # next step: keep a copy of it, not a reference
+            mean.update(gb, step.metrics, volatile=step.metrics is step.grads.tail)
         else:
             vals = torch.zeros(3, device=x.device)
             if hi > lo:
@@ -239,14 +305,19 @@ def train_main(script, args, build):
     p_net, q_net, rotate, translate, table)."""
     rank, world, local = dp.init_process_group(device_is_gpu=True)
     device = pick_device(args.device, world, local)
-    if getattr(args, "seed", None) is not None:     # an addition: reproducible runs (weights, shuffle, noise, augmentation)
-        torch.manual_seed(args.seed)
-        np.random.seed(args.seed % (2 ** 32))
-    # one seed for the whole job (rank 0's): the shuffle, the global noise draw and -- under DP -- everything drawn from
-    # np.random (the dataset shuffle of train_galaxy.py:372 inside build(), the augmentation angles) are then the same on
-    # every rank, which each slices [lo:hi)
-    seed = dp.shared_seed(device)
-    if world > 1:
+    # Randomness is consumed from torch's GLOBAL CPU generator and np.random in the order the reference's main() consumes
+    # them (SURVEY.md A.6): default initialisation of p_net then q_net, one draw for the sample-image pass over the validation
+    # loader, then per epoch the two draws of iter(DataLoader(shuffle=True)), one N(0,1) draw per training minibatch, one draw
+    # for the validation loader and one N(0,1) draw per validation minibatch (plus the display helpers' on dump epochs).  So
+    # torch.manual_seed(s) in front of this function -- or --seed s, an addition: the reference has no such flag -- follows the
+    # trajectory of the reference's CPU path under the same seed.  Under data-parallel execution every rank seeds alike
+    # (--seed, else rank 0's seed), makes the same draws and slices [lo:hi) of each global minibatch; np.random (the dataset
+    # shuffle of train_galaxy.py:372 inside build(), the augmentation angles) is seeded alike too.
+    seed = getattr(args, "seed", None)
+    if seed is None and world > 1:
+        seed = dp.shared_seed(device)
+    if seed is not None:
+        torch.manual_seed(seed)
         np.random.seed(seed % (2 ** 32))
     if getattr(args, "gemm", None):                 # before the first decoder call: buffer sizes depend on the mode
         from . import _lib
@@ -273,17 +344,16 @@ def train_main(script, args, build):
     num_epochs = args.num_epochs
     digits = int(math.log10(num_epochs)) + 1
     bs = args.minibatch_size
-    tr = {"y": cfg["y_train"].to(device), "ctf": None if cfg.get("ctf_train") is None else cfg["ctf_train"].to(device)}
-    te = {"y": cfg["y_test"].to(device), "ctf": None if cfg.get("ctf_test") is None else cfg["ctf_test"].to(device)}
+    # the dataset is resident in HBM (the reference preloads it too: train_mnist.py:329-332) unless --no-preload
+    # (train_particles.py:317, :405-413) keeps it in host memory, from where each minibatch is gathered and uploaded
+    home = torch.device("cpu") if getattr(args, "no_preload", False) else device
+    tr = {"y": cfg["y_train"].to(home), "ctf": None if cfg.get("ctf_train") is None else cfg["ctf_train"].to(home)}
+    te = {"y": cfg["y_test"].to(home), "ctf": None if cfg.get("ctf_test") is None else cfg["ctf_test"].to(home)}
     mask = cfg.get("mask")
     mask = mask.to(device) if mask is not None else None
     N = tr["y"].size(0)
-    if world > 1:       # every rank must hold the SAME resident dataset: the ranks slice one global minibatch by index
-        dp.assert_same_on_all_ranks(torch.stack([tr["y"].double().sum(), te["y"].double().sum()]), "the resident dataset")
-    gen = torch.Generator()
-    gen.manual_seed(seed)
-    noise_gen = torch.Generator(device=device)
-    noise_gen.manual_seed(seed)
+    if world > 1:       # every rank must hold the SAME dataset: the ranks slice one global minibatch by index
+        dp.assert_same_on_all_ranks(torch.stack([tr["y"].double().sum(), te["y"].double().sum()]).to(device), "the dataset")
     inf_dim = q_net.latent_dim
     out = sys.stdout
     header = cfg["table"]
@@ -292,29 +362,33 @@ def train_main(script, args, build):
     train_lines, val_lines = ["\t".join(header)], ["\t".join(header)]
     z_delay = getattr(args, "z_delay", 0)
     label = save_label(args) if out_dir else None
-    if out_dir:                                                      # MiscTools.sample_images: the first validation batch
-        export_batch_as_image(te["y"][:bs], "{}/images/_sample_{}.png".format(out_dir, label), [cfg["n"], cfg["m"]])
+    ntest = te["y"].size(0)
+    if script != "particles":                                        # MiscTools.sample_images: one pass is started over the
+        loader_order(ntest, False)                                   # validation loader (train_mnist.py:402) -> one draw
+        if out_dir:
+            export_batch_as_image(te["y"][:bs], "{}/images/_sample_{}.png".format(out_dir, label), [cfg["n"], cfg["m"]])
     for epoch in range(num_epochs):
         kw = {}
         if script != "mnist":
             kw["z_scale"] = 0 if epoch < z_delay else 1
-        perm = torch.randperm(N, generator=gen)                      # DataLoader(shuffle=True): same order on every rank
-        batches = [perm[i:i + bs].to(device) for i in range(0, N, bs)]
+        batches, noise = train_pass_plan(N, bs, inf_dim, device, home)    # same order and draws on every rank
         train_kw = {"augment_rotation": True} if cfg.get("augment") and script != "mnist" else {}
         t_epoch = time.time()
         e, g, k = run_epoch(script, step, x, batches, True, N, epoch, num_epochs, rank, world, args.progress_every,
-                            dict(data=tr, mask=mask, kw=kw, train_kw=train_kw, inf_dim=inf_dim, noise_gen=noise_gen))
+                            dict(data=tr, mask=mask, kw=kw, train_kw=train_kw, inf_dim=inf_dim, noise=noise))
         if rank == 0:       # run_epoch's values() synchronised: the epoch's training pass is complete
             print("# epoch {}: {} training images in {:.3f} s = {:.0f} images/s".format(
                 epoch + 1, N, time.time() - t_epoch, N / max(time.time() - t_epoch, 1e-9)), file=sys.stderr)
-        ntest = te["y"].size(0)
-        order = torch.arange(ntest)
-        tb = [order[i:i + bs].to(device) for i in range(0, ntest, bs)]
         dump = None
-        if out_dir and script != "particles" and (epoch + 1) % args.save_interval == 0:
-            dump = _image_dumper(script, step, x, cfg, out_dir, str(epoch + 1).zfill(digits), label, kw, args.z_dim)
+        shapes = None
+        if script != "particles" and (epoch + 1) % args.save_interval == 0:
+            # the display helpers' draws are made on every rank (one random stream), the files written by rank 0
+            shapes = display_draw_shapes(script, inf_dim, args.z_dim)
+        tb, noise, shown = eval_pass_plan(ntest, bs, inf_dim, device, home, shapes)
+        if shapes and out_dir:
+            dump = _image_dumper(script, step, x, cfg, out_dir, str(epoch + 1).zfill(digits), label, kw, args.z_dim, shown)
         ev = run_epoch(script, step, x, tb, False, ntest, epoch, num_epochs, rank, world, 0,
-                       dict(data=te, mask=mask, kw=kw, dump=dump, inf_dim=inf_dim, noise_gen=noise_gen))
+                       dict(data=te, mask=mask, kw=kw, dump=dump, inf_dim=inf_dim, noise=noise))
         if rank == 0:
             if script == "particles":
                 print("\t".join([str(epoch + 1), "train", str(e), str(g), str(k)]), file=out)
@@ -341,21 +415,35 @@ def train_main(script, args, build):
     return 0
 
 
-def _image_dumper(script, step, x, cfg, out_dir, epoch_str, label, kw, z_dim):
+def display_draw_shapes(script, inf_dim, z_dim):
+    """Shapes of the N(0,1) draws eval_model's image dump makes for a first minibatch of B images: minibatch_for_display
+    draws (B, inf_dim) (train_mnist.py:107, train_galaxy.py:146); galaxy's random_minibatch_generator then (B, z_dim)
+    (train_galaxy.py:177)."""
+    if script == "galaxy":
+        return lambda B: [(B, inf_dim), (B, z_dim)]
+    return lambda B: [(B, inf_dim)]
+
+
+def _image_dumper(script, step, x, cfg, out_dir, epoch_str, label, kw, z_dim, shown=(None, None)):
     """The PNG dumps of eval_model (train_mnist.py:214-224, train_galaxy.py:275-292): <epoch>_dis_ = decoded from the
     content latents on the unposed grid, <epoch>_ = the posed reconstruction y_hat of the same batch, galaxy also
-    <epoch>_rnd_ = decoded prior samples."""
+    <epoch>_rnd_ = decoded prior samples.  `shown`: the helpers' N(0,1) draws, made by pass_noise in the reference's order."""
     dims = [cfg["n"], cfg["m"]]
     p_net, q_net = step.p_net, step.q_net
+    shown = list(shown) + [None, None]
 
     def dump(y, y_hat):
         base = "{}/images/{}".format(out_dir, epoch_str)
+        rows = y.size(0)                        # data parallel: rank 0's slice [0, rows) of the first global minibatch
+        shown[0] = shown[0][:rows] if shown[0] is not None else None
+        shown[1] = shown[1][:rows] if shown[1] is not None else None
         if script == "mnist":
-            dis = E.minibatch_for_display(x, y, p_net, q_net, rotate=cfg["rotate"], translate=cfg["translate"])
+            dis = E.minibatch_for_display(x, y, p_net, q_net, rotate=cfg["rotate"], translate=cfg["translate"], noise=shown[0])
         else:
             zs = kw.get("z_scale", 1)
-            dis = E.minibatch_for_display_galaxy(x, y, q_net, p_net, rotate=cfg["rotate"], translate=cfg["translate"], z_scale=zs)
-            rnd = E.random_minibatch_generator(x, y, p_net, z_dim, z_scale=zs)
+            dis = E.minibatch_for_display_galaxy(x, y, q_net, p_net, rotate=cfg["rotate"], translate=cfg["translate"], z_scale=zs,
+                                                 noise=shown[0])
+            rnd = E.random_minibatch_generator(x, y, p_net, z_dim, z_scale=zs, noise=shown[1])
             export_batch_as_image(rnd, "{}_rnd_{}.png".format(base, label), dims)
         export_batch_as_image(dis, "{}_dis_{}.png".format(base, label), dims)
         if y_hat is not None:

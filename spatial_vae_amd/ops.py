@@ -133,9 +133,12 @@ class _Decoder(torch.autograd.Function):
                                                       _p(dll), _p(saved), ws.data_ptr(), ws.numel(), _stream(device)))
         ctx.spec, ctx.B, ctx.N = spec, B, N
         ctx.sinks = sinks
-        ctx.saved_buf = saved
-        ctx.dll = dll
-        ctx.tensors = (coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits)
+        # everything the backward call reads goes through save_for_backward, so the buffers have the lifetime the reference's
+        # autograd graph gives its activations (spatial_vae/models.py:90-132 is plain autograd): released after the first
+        # backward(), kept under retain_graph=True (any number of backward passes), and a second backward() without it raises
+        # torch's own "backward through the graph a second time" error
+        ctx.save_for_backward(coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, logits, saved,
+                              dll, *hidden)
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)      # an unused output (y when only loglik feeds the loss) arrives as None
         if loglik is None:
@@ -146,15 +149,17 @@ class _Decoder(torch.autograd.Function):
     def backward(ctx, dy, _dlogits, g_loglik=None):
         L = _lib.lib()
         spec, B, N = ctx.spec, ctx.B, ctx.N
-        coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, hidden, logits = ctx.tensors
+        (coords, grid, theta, dx, z, coord_w, coord_b, latent_w, bilinear_w, out_w, out_b, logits, saved_buf, dll,
+         *hidden) = ctx.saved_tensors
+        hidden = tuple(hidden)
         device = logits.device
         # what reaches the kernels: dy (B, N, C) and an optional per-image factor dy_scale (B)
         dy_scale = None
-        if ctx.dll is not None and g_loglik is not None:
+        if dll is not None and g_loglik is not None:
             if dy is None:
-                dy, dy_scale = ctx.dll, _f32(g_loglik).reshape(-1)      # the fused loss: d(loglik_b)/dy times its upstream gradient
+                dy, dy_scale = dll, _f32(g_loglik).reshape(-1)          # the fused loss: d(loglik_b)/dy times its upstream gradient
             else:
-                dy = _f32(dy) + ctx.dll * g_loglik.reshape(-1, 1, 1)    # y_hat is ALSO used downstream: add the two paths
+                dy = _f32(dy) + dll * g_loglik.reshape(-1, 1, 1)        # y_hat is ALSO used downstream: add the two paths
         elif dy is None:
             dy = torch.zeros((B, N, spec.n_out), dtype=torch.float32, device=device)
         dy = _f32(dy)
@@ -191,11 +196,9 @@ class _Decoder(torch.autograd.Function):
         ws = _buf(device, ws_bytes, "ws")
         with torch.cuda.device(device):
             _lib.check(L.svae_decoder_backward(ctypes.byref(desc), ctypes.byref(params), ctypes.byref(pose), _p(z),
-                                               logits.data_ptr(), dy.data_ptr(), _p(dy_scale), ctx.saved_buf.data_ptr(),
+                                               logits.data_ptr(), dy.data_ptr(), _p(dy_scale), saved_buf.data_ptr(),
                                                ctypes.byref(grads), _p(g_z), ctypes.byref(pg), ws.data_ptr(), ws.numel(),
                                                _stream(device)))
-        ctx.saved_buf = None
-        ctx.dll = None
         ready = sinks.get("__ready__")   # dp.TrainStep: every decoder gradient is now enqueued -> start its all-reduce
         if ready is not None:
             ready()
@@ -402,12 +405,12 @@ class _BceLoglik(torch.autograd.Function):
         with torch.cuda.device(y_hat.device):
             _lib.check(L.svae_bce_loglik(B, n, y_hat.data_ptr(), target.data_ptr(), loglik.data_ptr(), _p(dll),
                                          _stream(y_hat.device)))
-        ctx.dll = dll
+        ctx.save_for_backward(dll)
         return loglik
 
     @staticmethod
     def backward(ctx, g):
-        dll = ctx.dll
+        dll, = ctx.saved_tensors
         return dll * g.reshape((-1,) + (1,) * (dll.dim() - 1)), None
 
 
@@ -435,12 +438,13 @@ class _GaussianLoglik(torch.autograd.Function):
         with torch.cuda.device(y_params.device):
             _lib.check(L.svae_gaussian_loglik(B, N, C, y_params.data_ptr(), target.data_ptr(), _p(mask), _p(ctf), k,
                                               loglik.data_ptr(), _p(dll), _p(ws), ws_bytes, _stream(y_params.device)))
-        ctx.dll = dll
+        ctx.save_for_backward(dll)
         return loglik
 
     @staticmethod
     def backward(ctx, g):
-        return ctx.dll * g[:, None], None, None, None
+        dll, = ctx.saved_tensors
+        return dll * g[:, None], None, None, None
 
 
 def gaussian_loglik(y_params, target, mask=None, ctf=None):

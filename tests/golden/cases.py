@@ -317,3 +317,40 @@ def build_vanilla_inputs(case):
     out["y"] = y.astype(np.float32)
     out["r"] = rs.normal(size=(B, case["z_dim"])).astype(np.float32)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Seeded end-to-end runs (gen_seeded_golden.py): the reference's main() flow -- default initialisation, DataLoader(shuffle=True),
+# un-patched noise draws -- under torch.manual_seed(seed) / np.random.seed(seed), against the build's command lines with
+# `--seed seed --synthetic count`.  `argv` is the build's command line (this fork's flag spellings: underscores for
+# mnist/galaxy, hyphens for particles); the generator reads the same numbers from the fields beside it.
+def synthetic_images(kind, count, n, m, channels, seed):
+    """The `--synthetic` dataset of the three command lines (spatial_vae_amd/cli.py synthetic_images; a CPU test keeps the two
+    definitions equal)."""
+    rs = np.random.RandomState(seed)
+    if kind == "particles":
+        return rs.normal(size=(count, n, m)).astype(np.float32)
+    shape = (count, n, m) if channels == 1 else (count, n, m, channels)
+    u = rs.uniform(size=shape)
+    keep = rs.uniform(size=shape) > (0.8 if channels == 1 else 0.0)
+    return np.floor(u * keep * 255.0).astype(np.float32)
+
+
+SEEDED_CASES = [
+    dict(name="seeded_mnist", script="mnist", seed=1234, count=300, n=28, m=28, channels=1, z_dim=2, H=64, q_hidden=32, L=2,
+         q_layers=2, bs=64, epochs=2, lr=1e-3, save_interval=1, theta_prior=np.pi / 4, dx_scale=0.1, z_delay=0, augment=False,
+         argv=["--synthetic", "300", "--num_epochs", "2", "--minibatch_size", "64", "--p_hidden_dim", "64", "--q_hidden_dim", "32",
+               "-l", "1e-3", "--save_prefix", "s", "--save_interval", "1", "--progress_every", "0", "--seed", "1234"]),
+    dict(name="seeded_galaxy", script="galaxy", seed=77, count=48, n=32, m=32, channels=3, z_dim=4, H=32, q_hidden=32, L=3,
+         q_layers=1, bs=20, epochs=2, lr=1e-3, save_interval=1, theta_prior=np.pi, dx_scale=0.1, z_delay=1, augment=True,
+         argv=["x", "y", "--synthetic", "48", "--num_epochs", "2", "--minibatch_size", "20", "-z", "4", "--p_hidden_dim", "32",
+               "--q_hidden_dim", "32", "--p_num_layers", "3", "-l", "1e-3", "--z_delay", "1", "--augment_rotation",
+               "--save_prefix", "s", "--save_interval", "1", "--progress_every", "0", "--seed", "77"]),
+    dict(name="seeded_particles", script="particles", seed=4321, count=96, n=40, m=40, channels=1, z_dim=3, H=48, q_hidden=32,
+         L=2, q_layers=1, bs=40, epochs=2, lr=1e-3, save_interval=10, theta_prior=np.pi, dx_scale=0.1, z_delay=1, augment=False,
+         fit_noise=True,
+         argv=["x", "y", "--synthetic", "96", "--num-epochs", "2", "--minibatch-size", "40", "-z", "3", "--p-hidden-dim", "48",
+               "--q-hidden-dim", "32", "--p-num-layers", "2", "-l", "1e-3", "--z-delay", "1", "--fit-noise", "--progress-every",
+               "0", "--seed", "4321"]),
+]
+SEEDED_CASES_BY_NAME = {c["name"]: c for c in SEEDED_CASES}

@@ -151,3 +151,100 @@ def test_bench_starts_its_own_ranks_and_reports_their_failure():
         return
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+# ---------------------------------------------------------------------------------------------------- seeded runs (row R)
+def test_synthetic_dataset_definitions_agree():
+    import cases as C
+    from spatial_vae_amd import cli
+    for kind, n, ch in (("mnist", 28, 1), ("galaxy", 32, 3), ("particles", 40, 1)):
+        assert np.array_equal(cli.synthetic_images(kind, 7, n, n, ch, 3), C.synthetic_images(kind, 7, n, n, ch, 3))
+
+
+def test_loader_order_is_the_dataloaders():
+    """cli.loader_order consumes the global CPU generator exactly as iter(DataLoader) does and yields its order."""
+    from spatial_vae_amd import cli
+    data = torch.utils.data.TensorDataset(torch.arange(103))
+    for shuffle in (True, False):
+        torch.manual_seed(99)
+        want = torch.cat([b for b, in torch.utils.data.DataLoader(data, batch_size=10, shuffle=shuffle)])
+        after = torch.empty(5).normal_()
+        torch.manual_seed(99)
+        got = cli.loader_order(103, shuffle)
+        assert torch.equal(got, want)
+        assert torch.equal(torch.empty(5).normal_(), after)               # and leaves the generator in the same state
+
+
+def _replay_seeded_on_cpu(case):
+    """The build's random plan (cli.train_pass_plan / eval_pass_plan: shuffle + noise in the reference's order) driving the
+    torch-CPU port of the reference step, from the seed alone."""
+    import contextlib
+    import io
+    import cases as C
+    import spatial_vae.models as models
+    from oracle import torch_cpu_step as T
+    from spatial_vae_amd import cli
+    script, n, m = case["script"], case["n"], case["m"]
+    torch.manual_seed(case["seed"])
+    np.random.seed(case["seed"])
+    tr = cli.synthetic_images(script, case["count"], n, m, 1, 0)
+    te = cli.synthetic_images(script, max(case["count"] // 4, 1), n, m, 1, 1)
+    scale = 255.0 if script == "mnist" else 1.0
+    y_train = torch.from_numpy(tr).float().div(scale).view(-1, n * m)
+    y_test = torch.from_numpy(te).float().div(scale).view(-1, n * m)
+    inf_dim = case["z_dim"] + 3
+    with contextlib.redirect_stdout(io.StringIO()):
+        p_net = models.SpatialGenerator(case["z_dim"], case["H"], n_out=2 if case.get("fit_noise") else 1, num_layers=case["L"])
+        q_net = models.InferenceNetwork(n * m, inf_dim, case["q_hidden"], num_layers=case["q_layers"])
+    init_sum = float(sum(p.detach().double().sum() for p in list(p_net.parameters()) + list(q_net.parameters())))
+    trainer = T.CpuTrainer({k: v.detach().numpy() for k, v in p_net.state_dict().items()},
+                           {k: v.detach().numpy() for k, v in q_net.state_dict().items()}, cli.coord_grid(n, m), lr=case["lr"],
+                           script=script, act="tanh", rotate=True, translate=True, dx_scale=case["dx_scale"],
+                           theta_prior=case["theta_prior"])
+    cpu = torch.device("cpu")
+    if script != "particles":
+        cli.loader_order(len(y_test), False)                              # sample_images
+    steps, rows = [], []
+    for epoch in range(case["epochs"]):
+        kw = {} if script == "mnist" else {"z_scale": 0 if epoch < case["z_delay"] else 1}
+        mean = cli.RunningMean()
+        batches, noise = cli.train_pass_plan(len(y_train), case["bs"], inf_dim, cpu)
+        for idx, r in zip(batches, noise):
+            out = trainer.step(y_train[idx], r, **kw)
+            steps.append([float(v) for v in out])
+            mean.update(idx.numel(), torch.stack(out))
+        row = mean.values()
+        shapes = None
+        if script != "particles" and (epoch + 1) % case["save_interval"] == 0:
+            shapes = cli.display_draw_shapes(script, inf_dim, case["z_dim"])
+        tb, noise, _ = cli.eval_pass_plan(len(y_test), case["bs"], inf_dim, cpu, None, shapes)
+        mean = cli.RunningMean()
+        for idx, r in zip(tb, noise):
+            with torch.no_grad():
+                out = trainer.fn(trainer.pp, trainer.qp, trainer.x, y_test[idx], r, **dict(trainer.cfg, **kw))[:3]
+            steps.append([float(v) for v in out])
+            mean.update(idx.numel(), torch.stack(out))
+        rows.append(row + mean.values())
+    return init_sum, np.array(steps), np.array(rows), trainer
+
+
+def test_seeded_runs_follow_the_reference_from_the_seed_alone():
+    """Row R of the coverage table: with torch.manual_seed(s) the build consumes randomness in the reference's order --
+    default initialisation (p_net, q_net), the sample-image pass, DataLoader(shuffle=True)'s two draws per epoch, one N(0,1)
+    draw per minibatch on the CPU generator, the validation loader's draw, the display helpers' draws on dump epochs -- so the
+    torch-CPU port driven by cli's plan reproduces the reference's un-patched seeded run (tests/golden/gen_seeded_golden.py):
+    every step's (elbo, log_p, kl), the printed rows and the final parameters."""
+    import cases as C
+    from helpers import load_golden, rel_err
+    for name in ("seeded_mnist", "seeded_particles"):
+        case = C.SEEDED_CASES_BY_NAME[name]
+        gold = load_golden(name)
+        init_sum, steps, rows, trainer = _replay_seeded_on_cpu(case)
+        assert abs(init_sum - float(gold["init_sum"])) <= 1e-9 * max(1.0, abs(float(gold["init_sum"]))), name
+        assert steps.shape == gold["steps"].shape, name
+        assert np.abs(steps - gold["steps"]).max() <= 2e-5 * np.abs(gold["steps"]).max(), (name, steps, gold["steps"])
+        assert np.abs(rows - gold["rows"]).max() <= 2e-5 * np.abs(gold["rows"]).max(), name
+        for k, v in trainer.pp.items():
+            assert rel_err(v.detach().numpy(), gold["p." + k]) < 1e-4, (name, k)
+        for k, v in trainer.qp.items():
+            assert rel_err(v.detach().numpy(), gold["q." + k]) < 1e-4, (name, k)

@@ -44,6 +44,15 @@ def mnist_arguments(argv=None):
     return p.parse_args(argv)
 
 
+def dataset_files(dataset):
+    """(train, test) .npy paths of --dataset as the reference spells them (train_mnist.py:285-299): the MNIST variants are
+    data/<name>/images_{train,test}.npy, galaxy zoo is data/galaxy_zoo/galaxy_zoo_{train,test}.npy."""
+    if dataset == "galaxy":
+        return "data/galaxy_zoo/galaxy_zoo_train.npy", "data/galaxy_zoo/galaxy_zoo_test.npy"
+    sub = {"mnist-rotated": "mnist_rotated", "mnist-rotated-translated": "mnist_rotated_translated"}[dataset]
+    return "data/{}/images_train.npy".format(sub), "data/{}/images_test.npy".format(sub)
+
+
 def build(args, device):
     if args.synthetic > 0:
         tr = cli.synthetic_images("mnist", args.synthetic, 28, 28, 1, 0)
@@ -52,12 +61,9 @@ def build(args, device):
         raise SystemExit("--dataset mnist downloads through torchvision, which is not available here; "
                          "use the .npy datasets or --synthetic")
     else:
-        sub = {"mnist-rotated": "mnist_rotated", "mnist-rotated-translated": "mnist_rotated_translated",
-               "galaxy": "galaxy_zoo"}[args.dataset]
-        tr = np.load("data/{}/images_train.npy".format(sub))       # train_mnist.py:280-306
-        te = np.load("data/{}/images_test.npy".format(sub))
-        if tr.ndim == 4:                                            # galaxy-zoo as mnist: channel mean
-            tr, te = tr.mean(3), te.mean(3)
+        tr, te = (np.load(f) for f in dataset_files(args.dataset))
+        if args.dataset == "galaxy":                                # mono-chromed galaxy zoo: channel mean (train_mnist.py:297-301)
+            tr, te = np.mean(tr, axis=3), np.mean(te, axis=3)
     n, m = tr.shape[1:3]
     y_train = torch.from_numpy(tr).float().div(255).view(-1, n * m)
     y_test = torch.from_numpy(te).float().div(255).view(-1, n * m)

@@ -45,7 +45,8 @@ def particle_arguments(argv=None):
     p.add_argument("--save-interval", default=10, type=int)
     p.add_argument("--num-epochs", type=int, default=100)
     p.add_argument("-d", "--device", type=int, default=-2)
-    p.add_argument("--no-preload", action="store_true")
+    p.add_argument("--no-preload", action="store_true", help="do not preload data into GPU RAM: the dataset stays in host "
+                   "memory and each minibatch is uploaded")
     p.add_argument("--mask", action="store_true")
     p.add_argument("--synthetic", type=int, default=0, help="train on this many synthetic 40x40 particles (paths ignored)")
     p.add_argument("--progress-every", type=int, default=50)
