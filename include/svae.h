@@ -280,7 +280,8 @@ int svae_rotate_bicubic(const float* y, float* y_rot, const double* matrix, cons
  *   filters  (count, n, m) fp32 out -- the `ctf` operand of svae_gaussian_loglik.
  * Arithmetic is in doubles like numpy's; the result agrees with the reference to fp32 rounding.
  * Filters of up to ~80 x 80 are transformed entirely in the LDS of one CU and need no scratch (the workspace size is 0 and
- * ws may be NULL); larger ones (the reference's numpy code has no size limit) keep their intermediate planes in `ws`.
+ * ws may be NULL); larger ones keep their intermediate planes in `ws` and only the 2 (n + m) twiddle factors in LDS, so
+ * n + m <= 10240 (SVAE_E_INVALID beyond; the reference's numpy code has no size limit, cryo-EM boxes are a few hundred).
  */
 size_t svae_ctf_filter_workspace_bytes(int32_t count, int32_t n, int32_t m);
 int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, void* ws,
@@ -291,7 +292,8 @@ int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t
  * SVAE_GEMM_FP16X3: every operand as two half tensors (hi + lo, power-of-two scaled), three f16 MFMAs per product with
  * fp32 accumulation -- as accurate as an fp32 GEMM, ~1.8x faster per training step; taken for tanh /
  * sigmoid nets whose width is a multiple of 64, fp32 kernels otherwise.  The mode changes svae_saved_bytes and
- * svae_workspace_bytes: set it before sizing buffers, and do not change it between a forward call and its backward call.
+ * svae_workspace_bytes: set it before sizing buffers, and do not change it between a forward call and its backward call
+ * (svae_decoder_backward returns SVAE_E_INVALID when `saved` was planned under another mode or SVAE_FUSE_OUT setting).
  * Without a call the environment variable SVAE_GEMM (fp16x3 | anything else) decides at first use.
  */
 #define SVAE_GEMM_FP32 0

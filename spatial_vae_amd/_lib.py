@@ -16,15 +16,25 @@ FLAG_RESID, FLAG_BILINEAR, FLAG_SOFTPLUS = 1, 2, 4
 ABI_VERSION = 2
 
 
-def _declared_symbols():
-    """Every function include/svae.h declares -- build() and the tests check that the library exports all of them."""
+# every function include/svae.h declares; build() and tests/test_host_cpu.py re-derive this list from the header and check it
+# against the library's exports (the header is documentation: importing the package must not need it)
+EXPORTS = ("svae_abi_version", "svae_adam_step", "svae_bce_loglik", "svae_colsum", "svae_ctf_filter",
+           "svae_ctf_filter_workspace_bytes", "svae_decoder_backward", "svae_decoder_forward",
+           "svae_decoder_forward_bce", "svae_elbo_head_backward", "svae_elbo_head_forward", "svae_gaussian_loglik",
+           "svae_gaussian_workspace_bytes", "svae_gemm_mode_get", "svae_gemm_mode_set", "svae_last_error",
+           "svae_latent_backward", "svae_latent_forward", "svae_linear_backward", "svae_linear_forward",
+           "svae_path_counts", "svae_path_name", "svae_profile_enable", "svae_profile_kind_name",
+           "svae_profile_read", "svae_rotate_bicubic", "svae_saved_bytes", "svae_workspace_bytes")
+
+
+def declared_in_header(header=None):
+    """The function names include/svae.h declares (used by build() and the tests, never at import)."""
     import re
-    header = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "svae.h")
+    header = header or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "svae.h")
     with open(header) as f:
         return tuple(sorted(set(re.findall(r"\b(svae_[a-z0-9_]+)\s*\(", f.read()))))
 
 
-EXPORTS = _declared_symbols()
 PROF_KINDS = 20
 
 

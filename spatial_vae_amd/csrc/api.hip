@@ -7,7 +7,9 @@
 #include <math.h>
 #include <atomic>
 #include <mutex>
+#include <iterator>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -137,6 +139,37 @@ bool split_active(const Geo& g) {
 bool rank1_out(const Geo& g) {
     return fuse_out_mode() == 2 && !split_active(g) && g.C == 1 && g.L >= 2 && !(g.flags & SVAE_FLAG_RESID) &&
            (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID);
+}
+
+// What a forward call decided and baked into `saved` (rank-1 scaling of the packed data-gradient weights, fp16x3 operand
+// forms, the a0-fragments-only layout), remembered per `saved` pointer so that the backward call can refuse a buffer planned
+// under another GEMM mode or SVAE_FUSE_OUT setting instead of silently mixing the two (wrong gradients, no error).  A host-side
+// table: the library never reads device memory back.  Bounded: beyond 4096 live buffers the oldest records are dropped (their
+// backward calls then run unverified, as before).
+struct PlanBits {
+    unsigned bits;
+    unsigned long long seq;
+};
+std::mutex g_plan_mu;
+std::unordered_map<const void*, PlanBits> g_plans;
+unsigned long long g_plan_seq = 0;
+unsigned plan_bits(const Geo& g) {
+    return (rank1_out(g) ? 1u : 0u) | (split_active(g) ? 2u : 0u) | ((unsigned)fuse_out_mode() << 2) |
+           (split_a0_fragments_only(g) ? 16u : 0u) | ((split_mode() && split_l0_on()) ? 32u : 0u);
+}
+void remember_plan(const void* saved, unsigned bits) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_plans.size() >= 4096) {
+        const unsigned long long cut = g_plan_seq - 2048;
+        for (auto it = g_plans.begin(); it != g_plans.end();) it = it->second.seq < cut ? g_plans.erase(it) : std::next(it);
+    }
+    g_plans[saved] = PlanBits{bits, g_plan_seq++};
+}
+// -1: no record, else the recorded bits
+long recorded_plan(const void* saved) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(saved);
+    return it == g_plans.end() ? -1L : (long)it->second.bits;
 }
 
 Plan make_plan(const Geo& g, void* saved, void* ws) {
@@ -733,6 +766,8 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
     const PoseArgs pa = pose_args(pose);
     if (!saved) {  // inference only: ping-pong through the (otherwise unused) gradient buffers
         for (int l = 0; l < g.L; ++l) pl.act[l] = pl.dh[l & 1];
+    } else {
+        remember_plan(saved, plan_bits(g));
     }
 
     // the output layer's logits come out of the last hidden layer's epilogue (no second pass over a_{L-1}) whenever that
@@ -830,6 +865,13 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
     if (pg && (pg->dtheta || pg->ddx) && pose->coords)
         return fail(SVAE_E_INVALID, "dtheta/ddx requested but the pose was given as explicit coords");
     const Geo g = make_geo(*d);
+    {
+        const long rec = recorded_plan(saved);
+        if (rec >= 0 && (unsigned)rec != plan_bits(g))
+            return fail(SVAE_E_INVALID, "svae_decoder_backward: `saved` was written by a forward call planned differently (plan "
+                        "bits %ld then, %u now): the GEMM mode (svae_gemm_mode_set / SVAE_GEMM) or SVAE_FUSE_OUT changed between "
+                        "the forward call and its backward call", rec, plan_bits(g));
+    }
     const Plan pl = make_plan(g, const_cast<void*>(saved), ws);
     if ((rc = check_ws(pl, ws, ws_bytes))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1188,7 +1230,11 @@ size_t svae_ctf_filter_workspace_bytes(int32_t count, int32_t n, int32_t m) {
 int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t n, int32_t m, double scale, void* ws,
                     size_t ws_bytes, svae_stream_t stream) {
     if (!params || !filters || count < 1 || n < 1 || m < 1) return fail(SVAE_E_INVALID, "svae_ctf_filter: bad arguments");
-    if (n > 8192 || m > 8192) return fail(SVAE_E_INVALID, "svae_ctf_filter: %d x %d filters are not supported (max 8192)", n, m);
+    // the scratch form keeps only the 2 (n + m) twiddle factors in LDS: 16 (n + m) bytes must fit one CU's 160 KiB
+    const size_t tw = 2 * ((size_t)n + m) * sizeof(double);
+    if (tw > CTF_LDS_MAX)
+        return fail(SVAE_E_INVALID, "svae_ctf_filter: %d x %d filters are not supported (n + m must not exceed %zu)", n, m,
+                    CTF_LDS_MAX / (2 * sizeof(double)));
     if (!(scale > 0.0)) return fail(SVAE_E_INVALID, "svae_ctf_filter: scale must be positive");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = ctf_lds_bytes(n, m);
@@ -1205,8 +1251,11 @@ int svae_ctf_filter(const double* params, float* filters, int32_t count, int32_t
             return fail(SVAE_E_WORKSPACE, "svae_ctf_filter: %d x %d filters need %zu bytes of 256-byte aligned scratch (got %zu)",
                         n, m, need, ws_bytes);
         const int groups = count < CTF_SCRATCH_GROUPS ? count : CTF_SCRATCH_GROUPS;
-        hipLaunchKernelGGL(ctf_filter_kernel<true>, dim3(groups), dim3(256), 2 * ((size_t)n + m) * sizeof(double), st, params,
-                           filters, count, n, m, scale, static_cast<double*>(ws));
+        if (tw > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(ctf_filter_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tw) != hipSuccess)
+            return fail(SVAE_E_LAUNCH, "svae_ctf_filter: cannot reserve %zu bytes of LDS", tw);
+        hipLaunchKernelGGL(ctf_filter_kernel<true>, dim3(groups), dim3(256), tw, st, params, filters, count, n, m, scale,
+                           static_cast<double*>(ws));
     }
     return launch_status("svae_ctf_filter");
 }

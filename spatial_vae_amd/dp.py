@@ -20,6 +20,7 @@ second bucket (q_net + metrics) follows when backward() returns.
 Backend: "nccl" (= RCCL on ROCm) when the parameters live on a GPU, "gloo" on CPU (tests) and
 for the shared-GPU rehearsal (SVAE_SHARE_GPU=1: every rank on cuda:0).
 """
+import datetime
 import os
 import socket
 import subprocess
@@ -41,14 +42,21 @@ def init_process_group(device_is_gpu):
     share = os.environ.get("SVAE_SHARE_GPU") == "1"
     if share:
         local = 0
+    # a rank that never arrives at a collective (a dead peer, a wedged GPU) must end the job, not hang it: every collective
+    # of the group carries this limit (SVAE_DP_TIMEOUT seconds, default 300; launch_ranks has its own wall-clock limit on top)
+    limit = datetime.timedelta(seconds=int(os.environ.get("SVAE_DP_TIMEOUT", "300")))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if device_is_gpu and not share:
+            have = torch.cuda.device_count()        # counts devices without initialising the GPU
+            if have <= local:
+                raise SystemExit("spatial_vae_amd.dp: rank %d of %d needs GPU %d but this node shows %d device(s) "
+                                 "(one process per GPU: WORLD_SIZE must not exceed the GPUs of the node)" % (rank, world, local, have))
             torch.cuda.set_device(local)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=limit)
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=limit)
     elif world == 1 and solo_collectives() and device_is_gpu and not dist.is_initialized():
         # SVAE_DP_SOLO=1: a ONE-rank RCCL group whose collectives are really issued (see collectives_on)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -74,13 +82,18 @@ def collectives_on():
     return dist.is_initialized() and (dist.get_world_size() > 1 or solo_collectives())
 
 
-def launch_ranks(nproc, argv, env=None, poll=0.2):
+def launch_ranks(nproc, argv, env=None, poll=0.2, timeout=None):
     """Start `nproc` fresh Python processes running `argv` (script + arguments), one per GPU of this node, with RANK /
     LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them, and wait.  Returns 0
     when every rank exited 0, otherwise the first non-zero exit code (the remaining ranks are terminated: a dead peer
-    would leave them blocked in a collective).  The children inherit stdout/stderr, so rank 0's output is the job's.
-    The caller must not have touched the GPU: the children are new processes (fork + exec of the interpreter), never a
+    would leave them blocked in a collective).  `timeout` (seconds; default SVAE_LAUNCH_TIMEOUT or 1500) is a wall-clock
+    limit for the whole job: when it passes, every rank is terminated (killed if it ignores that) and 124 is returned -- one
+    rank stuck in a collective cannot hold the caller forever.  The children inherit stdout/stderr, so rank 0's output is the
+    job's.  The caller must not have touched the GPU: the children are new processes (fork + exec of the interpreter), never a
     re-exec of this one."""
+    if timeout is None:
+        timeout = float(os.environ.get("SVAE_LAUNCH_TIMEOUT", "1500"))
+    deadline = time.monotonic() + timeout
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -96,6 +109,13 @@ def launch_ranks(nproc, argv, env=None, poll=0.2):
     live = list(procs)
     while live:
         time.sleep(poll)
+        if time.monotonic() > deadline:
+            sys.stderr.write("spatial_vae_amd.dp.launch_ranks: %d rank(s) still running after %.0f s -- terminating the job\n"
+                             % (len(live), timeout))
+            for pr in live:
+                pr.terminate()
+            rc = rc or 124
+            break
         for pr in list(live):
             code = pr.poll()
             if code is None:

@@ -106,3 +106,29 @@ def test_launch_ranks_reports_a_failing_rank(tmp_path):
             "sys.exit(dp.launch_ranks(2, [%r]))" % (ROOT, str(script)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 7
+
+
+def test_launch_ranks_has_a_wall_clock_limit(tmp_path):
+    """A job whose ranks never finish (one stuck in a collective) is terminated at the limit and reported as 124."""
+    import time
+    script = tmp_path / "hang.py"
+    script.write_text("import time\ntime.sleep(300)\n")
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r], timeout=3))" % (ROOT, str(script)))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 124 and time.time() - t0 < 60
+    assert "terminating the job" in out.stderr
+
+
+def test_a_rank_without_a_gpu_of_its_own_fails_with_a_clear_message(tmp_path):
+    """init_process_group(device_is_gpu=True) checks torch.cuda.device_count() before joining the group: here there is no GPU at
+    all, so rank 1 of 2 must exit with the message, not hang in a rendezvous."""
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.update(RANK='1', LOCAL_RANK='1', WORLD_SIZE='2', "
+            "MASTER_ADDR='127.0.0.1', MASTER_PORT='29999'); os.environ.pop('SVAE_SHARE_GPU', None); "
+            "from spatial_vae_amd import dp; dp.init_process_group(device_is_gpu=True)" % ROOT)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "needs GPU 1" in out.stderr, out.stderr[-2000:]

@@ -36,10 +36,15 @@ def test_two_ranks_from_a_plain_invocation(scaling):
     # cfg 1 has 899,507 parameters; 12 tensors, each aligned to 64 floats in the flat buffer, + 3 metrics
     assert 4 * (899507 + 3) <= ar["bytes_per_step"] <= 4 * (899507 + 3 + 13 * 64)
     assert d["cpu_baseline"] is None and d["roofline"]["kernel"] in ("dense_fwd", "dense_dgrad", "wgrad")
+    # the record itself shows that both ranks joined the collectives (here both on cuda:0: the shared-GPU rehearsal)
+    assert ar["world"] == 2 and sorted(r for r, _ in ar["ranks_devices"]) == [0, 1]
 
 
 def test_single_gpu_line_carries_roofline_and_cpu_baseline():
-    d = _bench(["--config", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--no-secondary"])
+    d = _bench(["--config", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--no-secondary", "--sustained", "1.5"])
+    s = d["sustained"]          # >= 1.5 s of back-to-back steps after the timed window
+    assert s["seconds"] >= 1.5 and s["steps"] >= 100 and 0.5 * d["value"] < s["value"] < 1.5 * d["value"]
+    assert set(s["gemm_kernels_avg_ms"]) == {"dense_fwd", "dense_dgrad", "wgrad"} and 0.05 < s["roofline_frac"] < 1.0
     assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["unit"] == "images/s" and d["vs_baseline"] is None
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.05 < r["frac"] < 1.0
@@ -54,7 +59,7 @@ def test_every_baseline_config_has_a_bench_line(config, batch, kernel_min_frac):
     """`bench.py --config N` runs BASELINE configs 3 (fit-noise particles), 4 (galaxy RGB, three hidden layers, the 271 M
     parameter encoder that stays with the vendor GEMM) and 5 (particles with CTF filters built on the device) at their full
     sizes and reports the dominant GEMM against the fp32-MFMA peak."""
-    d = _bench(["--config", str(config), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"])
+    d = _bench(["--config", str(config), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--sustained", "0"])
     assert d["config"]["baseline_config"] == config and d["config"]["global_batch"] == batch
     assert d["value"] > 0 and d["dtype"] == "f32"
     r = d["roofline"]

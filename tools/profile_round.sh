@@ -9,7 +9,7 @@ TAG=${1:-r02}
 MODE=${SVAE_GEMM:-fp32}
 for c in 2 3 5 4; do
   steps=20; [ $c = 4 ] && steps=5
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_cfg$c -- python3 $R/bench.py --config $c --steps $steps --warmup 3 --no-cpu-baseline --no-secondary --no-profile --gemm $MODE > $R/gpurun_out/${TAG}_stats_cfg$c.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_cfg$c -- python3 $R/bench.py --config $c --steps $steps --warmup 3 --no-cpu-baseline --no-secondary --no-profile --sustained 0 --gemm $MODE > $R/gpurun_out/${TAG}_stats_cfg$c.log 2>&1
   grep "^{" $R/gpurun_out/${TAG}_stats_cfg$c.log | cut -c1-220
   python3 $R/tools/trace_summary.py $R/gpurun_out/${TAG}_stats_cfg$c --steps $steps > $R/gpurun_out/${TAG}_trace_summary_cfg$c.txt 2>&1
   head -8 $R/gpurun_out/${TAG}_trace_summary_cfg$c.txt
