@@ -30,8 +30,25 @@ FULL = [
 
 
 def _case(name, kw):
-    base = C._case(name, q_hidden=64, q_layers=1, seed=77, **kw)
-    return base
+    """The encoder has the width bench.py gives the config (500 x 2; the galaxy script's default 5000 x 2 for cfg 4,
+    train_galaxy.py:306): cfg 4's 49 152 x 5 000 and 5 000 x 5 000 layers take ops.sink_linear (hipBLASLt + svae_colsum), the
+    others the enc_linear kernels -- the branches the benchmark itself runs."""
+    wide = kw.get("script") == "galaxy"
+    return C._case(name, q_hidden=5000 if wide else 500, q_layers=2, seed=77, **kw)
+
+
+def _encoder_grads_float64(case, inp, g_q_out):
+    """d(-elbo)/d(q_net parameters) in float64 on the CPU: the encoder is a plain MLP (models.py:24-54), so backpropagate the
+    oracle's d(-elbo)/d(q_out) through a float64 copy of it."""
+    st = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in inp["q_state"].items()}
+    names = sorted({k.rsplit(".", 1)[0] for k in st}, key=lambda n: int(n.split(".")[1]))
+    h = torch.from_numpy(inp["y"]).double().reshape(inp["y"].shape[0], -1)
+    for i, nm in enumerate(names):
+        h = torch.nn.functional.linear(h, st[nm + ".weight"], st[nm + ".bias"])
+        if i + 1 < len(names):
+            h = torch.tanh(h)
+    h.backward(torch.from_numpy(g_q_out).double())
+    return {k: v.grad.numpy() for k, v in st.items()}
 
 
 def _run_gpu(case, inp):
@@ -41,7 +58,7 @@ def _run_gpu(case, inp):
     with contextlib.redirect_stdout(io.StringIO()):
         p_net = models.SpatialGenerator(case["z_dim"], case["H"], n_out=case["n_out"], num_layers=case["L"], activation=nn.Tanh)
         n_in = case["n"] * case["m"] * (case["n_out"] if case["script"] == "galaxy" else 1)
-        q_net = models.InferenceNetwork(n_in, C.inf_dim(case), case["q_hidden"], num_layers=1, activation=nn.Tanh)
+        q_net = models.InferenceNetwork(n_in, C.inf_dim(case), case["q_hidden"], num_layers=case["q_layers"], activation=nn.Tanh)
     p_net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["p_state"].items()})
     q_net.load_state_dict({k: torch.from_numpy(v) for k, v in inp["q_state"].items()})
     p_net.to(dev)
@@ -51,17 +68,31 @@ def _run_gpu(case, inp):
     r = torch.from_numpy(inp["r"]).to(dev)
     kw = dict(rotate=case["rotate"], translate=case["translate"], dx_scale=case["dx_scale"], theta_prior=case["theta_prior"],
               noise=r, return_logits=True)
-    if case["script"] == "mnist":
-        elbo, log_p, kl, _, logits = E.eval_minibatch_mnist(x, y, p_net, q_net, **kw)
-    elif case["script"] == "galaxy":
-        elbo, log_p, kl, _, logits = E.eval_minibatch_galaxy(x, y, p_net, q_net, **kw)
-    else:
-        ctf = torch.from_numpy(inp["ctf"]).to(dev) if inp["ctf"] is not None else None
-        elbo, log_p, kl, logits = E.eval_minibatch_particles(x, y, None, ctf, p_net, q_net, **kw)
+    kept = {}
+    orig_encode = E._encode
+
+    def keeping_encode(q, y2d):         # the encoder output as the ELBO sees it, with its gradient retained
+        out = orig_encode(q, y2d)
+        out.retain_grad()
+        kept["q_out"] = out
+        return out
+
+    E._encode = keeping_encode
+    try:
+        if case["script"] == "mnist":
+            elbo, log_p, kl, _, logits = E.eval_minibatch_mnist(x, y, p_net, q_net, **kw)
+        elif case["script"] == "galaxy":
+            elbo, log_p, kl, _, logits = E.eval_minibatch_galaxy(x, y, p_net, q_net, **kw)
+        else:
+            ctf = torch.from_numpy(inp["ctf"]).to(dev) if inp["ctf"] is not None else None
+            elbo, log_p, kl, logits = E.eval_minibatch_particles(x, y, None, ctf, p_net, q_net, **kw)
+    finally:
+        E._encode = orig_encode
     (-elbo).backward()
     torch.cuda.synchronize()
-    with torch.no_grad():
-        q_out = q_net.layers(y.view(y.size(0), -1)).cpu().numpy()
+    q_out = kept["q_out"].detach().cpu().numpy()
+    _run_gpu.last = dict(g_q_out=kept["q_out"].grad.detach().cpu().numpy(),
+                         gq={k: p.grad.detach().cpu().numpy() for k, p in q_net.named_parameters()})
     grads = {k: p.grad.detach().cpu().numpy() for k, p in p_net.named_parameters()}
     return elbo.item(), log_p.item(), kl.item(), logits.detach().cpu().numpy(), grads, q_out, (p_net, q_net, x, y, r)
 
@@ -76,9 +107,26 @@ def test_full_size_matches_oracle(name, kw):
                            theta_prior=case["theta_prior"], ctf=inp["ctf"])
     assert abs(elbo - float(ref["elbo"])) <= 1e-4 * abs(float(ref["elbo"]))
     assert abs(log_p - float(ref["log_p"])) <= 1e-4 * abs(float(ref["log_p"]))
+    assert abs(kl - float(ref["kl"])) <= 1e-4 * abs(float(ref["kl"]))
     assert rel_err(logits, ref["logits"]) < 1e-4
     for k, g in grads.items():
         assert rel_err(g, ref["gP"][k]) < 2e-4, (name, k, rel_err(g, ref["gP"][k]))
+    # the encoder side: the gradient that flows back into q_net (decoder pose / latent gradients + both KL terms), then
+    # every q_net parameter gradient against a float64 backward of the same MLP from the oracle's d(-elbo)/d(q_out)
+    got = _run_gpu.last
+    assert rel_err(got["g_q_out"], ref["g_q_out"]) < 2e-4, rel_err(got["g_q_out"], ref["g_q_out"])
+    # the encoder's own output against float64 (fp32 sums over up to 49 152 inputs: ~1e-6 relative to the largest entry)
+    with torch.no_grad():
+        st = {k: torch.from_numpy(v).double() for k, v in inp["q_state"].items()}
+        names = sorted({k.rsplit(".", 1)[0] for k in st}, key=lambda n: int(n.split(".")[1]))
+        h = torch.from_numpy(inp["y"]).double().reshape(inp["y"].shape[0], -1)
+        for i, nm in enumerate(names):
+            h = torch.nn.functional.linear(h, st[nm + ".weight"], st[nm + ".bias"])
+            h = torch.tanh(h) if i + 1 < len(names) else h
+    assert rel_err(q_out, h.numpy()) < 2e-5, rel_err(q_out, h.numpy())
+    want = _encoder_grads_float64(case, inp, ref["g_q_out"])
+    for k, g in got["gq"].items():
+        assert rel_err(g, want[k]) < 2e-4, (name, k, rel_err(g, want[k]))
 
 
 # BASELINE.json's configs at their FULL batch sizes: too big for the numpy oracle, so they are checked through a
