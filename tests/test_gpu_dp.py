@@ -257,3 +257,31 @@ def test_one_rank_rccl_group_executes_the_collectives_and_changes_nothing(tmp_pa
         assert "backend nccl collectives True" in outs[mode][0]
         a, b = outs["plain"][1], outs[mode][1]
         assert torch.equal(a["flat"], b["flat"]) and torch.equal(a["metrics"], b["metrics"]), mode
+
+
+def test_epoch_log_of_the_one_rank_rccl_run_equals_the_plain_run(tmp_path):
+    """The per-epoch TRAINING means are collected lazily from step.metrics; in every data-parallel mode -- including the one-rank
+    RCCL rehearsal (world == 1!) -- that is the shared metric tail of the gradient buffer, overwritten by each step, so the
+    loop must keep a copy per step (r02 kept references whenever world == 1: the logged means were the last step's values
+    repeated).  Same --seed, SVAE_DP_SOLO=1 against the plain run: the printed tables must agree line for line."""
+    import numpy as np
+    args = ["--synthetic", "200", "--num_epochs", "2", "--minibatch_size", "64", "--p_hidden_dim", "64", "--q_hidden_dim", "32",
+            "--progress_every", "0", "--save_interval", "100", "--seed", "21", "-l", "1e-3"]
+    script = os.path.join(ROOT, "train_mnist.py")
+    tables = {}
+    for mode in ("plain", "solo"):
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU", "SVAE_DP_SOLO"):
+            env.pop(k, None)
+        if mode == "solo":
+            env["SVAE_DP_SOLO"] = "1"
+        out = subprocess.run([sys.executable, script] + args + ["--save_prefix", mode], cwd=str(tmp_path), env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        rows = [l.split("\t") for l in out.stdout.splitlines() if "\t" in l]
+        tables[mode] = np.array([[float(v) for v in r] for r in rows[1:]])
+    a, b = tables["plain"], tables["solo"]
+    assert a.shape == b.shape == (4, 4)
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max(), (a, b)
+    # and the four minibatches of an epoch do differ, so a repeated last value could not have passed
+    assert abs(a[0, 1] - a[2, 1]) > 1e-3 * abs(a[0, 1])

@@ -87,3 +87,63 @@ def test_geometry_against_oracle(geom):
     gq = {k: p.grad.cpu().numpy() for k, p in q_net.named_parameters()}
     last = [k for k in gq if k.endswith("bias")][-1]
     assert rel_err(gq[last], ref["g_q_out"].sum(0)) < 1e-4
+
+
+def test_second_backward_follows_autograd_semantics():
+    """The reference's decoder is plain autograd (spatial_vae/models.py:90-132): backward(retain_graph=True) may be followed by
+    further backward passes through the same graph, and a second pass without it raises torch's "backward through the graph a
+    second time" error.  The HIP decoder keeps what its backward call reads in autograd's saved tensors, so it behaves the same."""
+    import contextlib
+    import io
+    import spatial_vae.models as models
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = models.SpatialGenerator(3, 40, num_layers=2).to(dev)
+    x = (torch.rand(5, 49, 2, device=dev) * 2 - 1).requires_grad_(True)
+    z = torch.randn(5, 3, device=dev, requires_grad=True)
+    up = torch.randn(5, 49, 1, device=dev)
+
+    def grads():
+        g = [q.grad.clone() for q in p.parameters()] + [x.grad.clone(), z.grad.clone()]
+        p.zero_grad(set_to_none=True)
+        x.grad = z.grad = None
+        return g
+
+    y = p(x, z)
+    y.backward(up, retain_graph=True)
+    first = grads()
+    y.backward(up, retain_graph=True)              # the saved buffers are still there
+    second = grads()
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    y.backward(2.0 * up)                           # last pass: releases them
+    third = grads()
+    for a, b in zip(first, third):
+        assert rel_err(b.cpu().numpy(), 2.0 * a.cpu().numpy()) < 1e-6
+    with pytest.raises(RuntimeError, match="second time|already been freed"):
+        y.backward(up)
+
+
+def test_backward_refuses_a_saved_buffer_planned_under_another_mode(monkeypatch):
+    """svae_decoder_backward re-derives the kernel plan from the descriptor, the GEMM mode and SVAE_FUSE_OUT; the forward call
+    baked some of those decisions into `saved` (row-scaled packed weights for the rank-1 output backward).  Changing
+    SVAE_FUSE_OUT between the two calls used to mix the forms silently; now the backward call fails with SVAE_E_INVALID."""
+    import contextlib
+    import io
+    import spatial_vae.models as models
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = models.SpatialGenerator(2, 40, num_layers=2).to(dev)       # one output channel, tanh: the rank-1 form applies
+    x = torch.rand(4, 49, 2, device=dev) * 2 - 1
+    z = torch.randn(4, 2, device=dev)
+    monkeypatch.delenv("SVAE_FUSE_OUT", raising=False)
+    y = p(x, z)
+    monkeypatch.setenv("SVAE_FUSE_OUT", "0")
+    with pytest.raises(RuntimeError, match="planned differently"):
+        y.sum().backward()
+    monkeypatch.delenv("SVAE_FUSE_OUT", raising=False)
+    p.zero_grad(set_to_none=True)
+    p(x, z).sum().backward()                                          # and a consistent pair still works
+    assert all(torch.isfinite(q.grad).all() for q in p.parameters())
