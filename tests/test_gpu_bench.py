@@ -51,7 +51,7 @@ def test_single_gpu_line_carries_roofline_and_cpu_baseline():
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread"]["value"] > 0
-    assert "median" in c["sample"] and "2 warm-ups" in c["sample"]
+    assert "median" in c["sample"] and "2 warm-up" in c["sample"]
 
 
 @pytest.mark.parametrize("config,batch,kernel_min_frac", [(3, 512, 0.5), (4, 128, 0.6), (5, 256, 0.5)])
