@@ -343,7 +343,7 @@ def main():
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 step.comm_events = pair
                 comm_pairs.append(pair)
-            step(x, *batch(i), weight=weight)
+            step(x, *batch(i), weight=weight, global_batch=global_B)
         step.comm_events = None
 
     if args.graph:
@@ -447,12 +447,17 @@ def main():
                           "decoder_mfma_frac_of_step": round(f_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
                "roofline": roofline}
         if dp.collectives_on():     # N > 1, or the one-rank RCCL rehearsal (SVAE_DP_SOLO=1)
-            nbytes = step.grads.buffer.numel() * 4
+            segs = step.allreduce_segments()
+            nbytes = 4 * sum(hi - lo for lo, hi in segs)
             out["allreduce"] = {**(joined or {"world": 1, "ranks_devices": [[0, dev.index]]}),
-                                "bytes_per_step": nbytes,
-                                "buckets_bytes": [step.n_p * 4, nbytes - step.n_p * 4] if step._bucketed else [nbytes],
+                                "bytes_per_step": nbytes, "buckets_bytes": [4 * (hi - lo) for lo, hi in segs],
+                                "gradient_bytes": step.grads.buffer.numel() * 4,
                                 "backend": dist.get_backend(),
                                 "compute_stream_wait_ms_per_step": round(sum(comm_ms) / max(len(comm_ms), 1), 4)}
+        if dp.collectives_on() and step._lowrank is not None:
+            # large encoder layers: the factors (x, dy) of dW are all-gathered and dW formed locally (dp.LowRankExchange)
+            out["allgather"] = {"bytes_per_step": step._lowrank.bytes_last, "layers": sorted(step._lowrank.keys),
+                                "replaces_allreduce_bytes": out["allreduce"]["gradient_bytes"] - out["allreduce"]["bytes_per_step"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds, ctf_filters.cpu() if ctf_filters is not None else None)
         else:

@@ -268,7 +268,7 @@ def run_epoch(script, step, x, batches, train, N, epoch, num_epochs, rank, world
             kw.update(extra.get("train_kw", {}))        # augmentation applies to training steps only (train_galaxy.py:204)
             if world > 1 and kw.get("augment_rotation") and step.eval_kwargs.get("rotate"):
                 kw["offset"] = E.draw_offsets(step.eval_kwargs["rotate"], gb)[lo:hi]   # np.random is seeded alike on all ranks
-            out = step(x, *args, weight=(hi - lo) / gb, **kw)
+            out = step(x, *args, weight=(hi - lo) / gb, global_batch=gb, **kw)
             # the data-parallel metric tail (also the one-rank RCCL rehearsal, and any weight != 1) is overwritten by the
             # next step: keep a copy of it, not a reference
             mean.update(gb, step.metrics, volatile=step.metrics is step.grads.tail)

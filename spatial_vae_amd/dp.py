@@ -231,6 +231,72 @@ def assert_same_on_all_ranks(t, what):
                            % (what, lo.tolist(), hi.tolist()))
 
 
+class LowRankExchange(object):
+    """Data-parallel weight gradients of LARGE Linear layers without moving the gradient.
+
+    dW = dy^T x has rank <= the number of rows (images) behind it.  For the galaxy encoder (BASELINE configs[3]:
+    InferenceNetwork(49152, 23, 5000, 2), train_galaxy.py:306, :461-470) the flat gradient is 1.09 GB, 983 MB of it the
+    49 152 x 5 000 first layer whose gradient is the LAST to complete -- an all-reduce nothing can hide.  But with a global
+    minibatch of 128 that gradient is a sum of 128 outer products: each rank contributes its rows of the two factors
+    (x: B_local x n_in, dy: B_local x n_out, already weighted local/global through the backward seed), ONE all-gather moves
+    B_global x (n_in + n_out) floats per layer (27.7 MB + 5.1 MB for the two large layers) and every rank forms the GLOBAL
+    dW = dy_all^T x_all and db = colsum(dy_all) locally (63 GF + 6 GF).  Every rank multiplies the same gathered matrices in
+    the same order, so the replicas stay bit-equal; against the one-rank run the sum over images is merely associated
+    differently (fp32 rounding).  Ragged and empty shards are zero-padded to cap = ceil(B_global / world) rows.
+    Used for the Linear layers that already take ops.sink_linear (more than ops.ENC_LINEAR_MAX_WEIGHT weights); their
+    parameter ranges are left out of the step's all-reduce (TrainStep._segments)."""
+
+    def __init__(self, layers, device):
+        # layers: [(key, sink_w, sink_b)] with sink_w (n_out, n_in)
+        self.layers = list(layers)
+        self.keys = {k for k, _, _ in self.layers}
+        self.device = device
+        self.width = sum(w.size(0) + w.size(1) for _, w, _ in self.layers)
+        self.pending = {}
+        self._send = self._recv = None
+        self.bytes_last = 0
+
+    def has(self, key):
+        return key in self.keys
+
+    def add(self, key, x, dy):
+        self.pending[key] = (x.detach(), dy.detach())
+
+    def start(self, cap):
+        """Pack this rank's factors (zero rows beyond its own, all zeros for an empty shard) and start the all-gather."""
+        world = dist.get_world_size()
+        if self._send is None or self._send.size(0) != cap:
+            self._send = torch.zeros(cap, self.width, dtype=torch.float32, device=self.device)
+            self._recv = torch.empty(world * cap, self.width, dtype=torch.float32, device=self.device)
+        else:
+            self._send.zero_()
+        off = 0
+        for key, w, _ in self.layers:
+            n_out, n_in = w.shape
+            if key in self.pending:
+                x, dy = self.pending[key]
+                rows = x.size(0)
+                if rows > cap:
+                    raise RuntimeError("LowRankExchange: %d local rows but the global minibatch allows %d per rank" % (rows, cap))
+                self._send[:rows, off:off + n_in].copy_(x)
+                self._send[:rows, off + n_in:off + n_in + n_out].copy_(dy)
+            off += n_in + n_out
+        self.pending = {}
+        self.bytes_last = self._recv.numel() * 4
+        return dist.all_gather_into_tensor(self._recv, self._send, async_op=True)
+
+    def finish(self):
+        """dW and db of every large layer from the gathered factors, written into the flat gradient buffer."""
+        off = 0
+        for _, w, b in self.layers:
+            n_out, n_in = w.shape
+            xa = self._recv[:, off:off + n_in]
+            dya = self._recv[:, off + n_in:off + n_in + n_out]
+            torch.mm(dya.t(), xa, out=w)
+            torch.sum(dya, 0, out=b)
+            off += n_in + n_out
+
+
 class TrainStep(object):
     """forward + backward + (all-reduce) + Adam step for one (local) minibatch.
 
@@ -240,8 +306,9 @@ class TrainStep(object):
     torch.optim.Adam is unchanged; it simply sees ONE parameter (the flat buffer every module
     parameter is a view of), which is the same element-wise update in one kernel.
 
-    Data parallel (see the module docstring): call with this rank's slice of the global minibatch and
-    weight = local_rows / global_rows.  The weight enters as the seed of backward() (-weight instead of -1: no
+    Data parallel (see the module docstring): call with this rank's slice of the global minibatch,
+    weight = local_rows / global_rows and global_batch = global_rows (needed by a rank whose slice is empty when large encoder
+    layers exchange gradient factors: LowRankExchange).  The weight enters as the seed of backward() (-weight instead of -1: no
     scaling pass over the gradient buffer).  A rank whose slice is EMPTY (ragged last batch smaller than the world)
     skips forward and backward but still joins both collectives with zeros.  After the call `metrics` holds
     (elbo, log_p, kl) of the GLOBAL minibatch on every rank, valid until the next call.
@@ -282,8 +349,32 @@ class TrainStep(object):
             p_net._grad_sinks["__ready__"] = self._decoder_grads_ready
             if q_sinks:
                 q_net._grad_sinks = {k: v for k, v in self.grads.sinks.items() if k in q_sinks}
-        self._seeds = {}
         self.device = params[0].device
+        # Large encoder layers (those elbo._encode runs through ops.sink_linear) exchange the factors of their weight gradient
+        # instead of the gradient (LowRankExchange); SVAE_DP_LOWRANK=0 keeps them in the all-reduce.
+        self._lowrank = None
+        skip = set()
+        if on_gpu and q_sinks and collectives_on() and os.environ.get("SVAE_DP_LOWRANK") != "0":
+            from .ops import ENC_LINEAR_MAX_WEIGHT
+            big = []
+            for idx, m in enumerate(q_net.layers):
+                if isinstance(m, torch.nn.Linear) and m.bias is not None and m.weight.numel() > ENC_LINEAR_MAX_WEIGHT:
+                    big.append(("layers.%d" % idx, self.grads.sinks["layers.%d.weight" % idx], self.grads.sinks["layers.%d.bias" % idx]))
+                    skip.update((id(m.weight), id(m.bias)))
+            if big:
+                self._lowrank = LowRankExchange(big, self.device)
+                q_net._grad_sinks["__lowrank__"] = self._lowrank
+        # element ranges of the gradient buffer that go through the all-reduce: everything except the low-rank layers; the
+        # metric tail rides at the end of the last range
+        self._segments = []
+        lo = 0
+        for p, off in zip(self.grads.params, self.grads.offsets):
+            if id(p) in skip:
+                if off > lo:
+                    self._segments.append((lo, off))
+                lo = (off + p.numel() + FlatGrads.ALIGN - 1) // FlatGrads.ALIGN * FlatGrads.ALIGN
+        self._segments.append((lo, self.grads.buffer.numel()))
+        self._seeds = {}
         self.master = torch.nn.Parameter(self.grads.flat_param)
         self.master.grad = self.grads.flat
         if on_gpu and fused_adam is None:
@@ -325,20 +416,44 @@ class TrainStep(object):
                 return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
 
-    def _reduce(self):
+    def allreduce_segments(self):
+        """(lo, hi) element ranges of the gradient buffer, in launch order, that this step all-reduces: the decoder's bucket
+        first when it goes out early, then every other range outside the low-rank layers (the metric tail is in the last)."""
+        segs = list(self._segments)
+        if self._bucketed:
+            out = [(0, self.n_p)]
+            for lo, hi in segs:
+                lo = max(lo, self.n_p)
+                if hi > lo:
+                    out.append((lo, hi))
+            return out
+        return segs
+
+    def _reduce(self, global_batch=None):
         if not collectives_on():
             return
         ev = self.comm_events
+        segs = self.allreduce_segments()
+        work = []
         if self._bucketed:
             if self._work_p is None:                      # empty shard (no backward ran): join the first bucket too
                 self._work_p = self._launch(self.grads.buffer[:self.n_p], side=True)
-            if ev:
-                ev[0].record()
-            work = [self._work_p, self._launch(self.grads.buffer[self.n_p:], side=False)]
-        else:
-            if ev:
-                ev[0].record()
-            work = [self._launch(self.grads.buffer, side=False)]
+            work.append(self._work_p)
+            segs = segs[1:]
+        if ev:
+            ev[0].record()
+        gather = None
+        if self._lowrank is not None:
+            # the factors first: the local GEMMs that follow then run under the remaining all-reduce
+            world = dist.get_world_size()
+            if global_batch is None:
+                raise RuntimeError("TrainStep: the low-rank gradient exchange needs global_batch= (rows of the GLOBAL minibatch)")
+            gather = self._lowrank.start((int(global_batch) + world - 1) // world)
+        for lo, hi in segs:
+            work.append(self._launch(self.grads.buffer[lo:hi], side=False))
+        if gather is not None:
+            gather.wait()
+            self._lowrank.finish()
         for w in work:
             w.wait()                                      # the compute stream waits; the host does not
         if ev:
@@ -353,7 +468,11 @@ class TrainStep(object):
 
     def _step(self, x, batch, weight, kw):
         out = None
+        kw = dict(kw)
+        global_batch = kw.pop("global_batch", None)
         rows = batch[0].size(0) if torch.is_tensor(batch[0]) else 1
+        if global_batch is None and weight > 0:
+            global_batch = int(round(rows / weight))
         if rows > 0:
             args = dict(self.eval_kwargs)
             args.update(kw)
@@ -371,7 +490,7 @@ class TrainStep(object):
         else:
             self.grads.tail.zero_()
             self.metrics = self.grads.tail
-        self._reduce()
+        self._reduce(global_batch)
         self.optim.step()
         self.grads.zero(already_cleared=getattr(self.optim, "zero_grad_in_step", False))
         return out
@@ -406,6 +525,7 @@ class TrainStep(object):
         return self
 
     def _replay(self, x, batch, weight, kw):
+        kw = {k: v for k, v in kw.items() if k != "global_batch"}
         if weight != 1.0 or kw:
             raise RuntimeError("a captured step replays fixed arguments")
         for dst, src in zip(self._static_batch, batch):

@@ -60,7 +60,10 @@ def _encode(q_net, y2d):
                     idx += 2 if act is not None else 1
                     continue
                 if sw is not None:
-                    h = ops.sink_linear(h, m.weight, m.bias, sw, sb)
+                    # data parallel: a layer this large exchanges the two factors of its weight gradient, not the gradient
+                    coll = sinks.get("__lowrank__")
+                    key = "layers.%d" % idx
+                    h = ops.sink_linear(h, m.weight, m.bias, sw, sb, coll if (coll is not None and coll.has(key)) else None, key)
                     idx += 1
                     continue
             h = m(h)

@@ -362,12 +362,17 @@ def enc_linear(x, weight, bias, act=None, sink_w=None, sink_b=None):
 class _SinkLinear(torch.autograd.Function):
     """y = x W^T + b; the backward pass writes dW and db straight into caller-owned gradient views (slices of the flat
     buffer of dp.FlatGrads) with torch.mm(out=) / torch.sum(out=) instead of returning tensors that autograd would then
-    ADD into those views: one kernel less per parameter per step.  The arithmetic is torch's (hipBLASLt)."""
+    ADD into those views: one kernel less per parameter per step.  The arithmetic is torch's (hipBLASLt).
+
+    With a `collector` (data-parallel runs: dp.LowRankExchange) the backward pass does not form dW at all: it hands its two
+    factors (x, dy) to the collector, and the step all-gathers the factors of every rank and forms the GLOBAL dW = dy_all^T
+    x_all locally -- rank <= global batch, a few MB on the wire instead of the weight's size."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, sink_w, sink_b):
+    def forward(ctx, x, weight, bias, sink_w, sink_b, collector=None, key=None):
         ctx.save_for_backward(x, weight)
         ctx.sinks = (sink_w, sink_b)
+        ctx.collector, ctx.key = collector, key
         return torch.addmm(bias, x, weight.t())
 
     @staticmethod
@@ -375,17 +380,20 @@ class _SinkLinear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         sink_w, sink_b = ctx.sinks
         dx = dy.mm(weight) if ctx.needs_input_grad[0] else None
+        if ctx.collector is not None:
+            ctx.collector.add(ctx.key, x, dy)
+            return dx, None, None, None, None, None, None
         torch.mm(dy.t(), x, out=sink_w)
         if dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and sink_b.is_contiguous():
             with torch.cuda.device(dy.device):   # column sums in ~3 us (ATen's reduce kernel takes 13 us for 256 x 500)
                 _lib.check(_lib.lib().svae_colsum(dy.data_ptr(), dy.size(0), dy.size(1), sink_b.data_ptr(), _stream(dy.device)))
         else:
             torch.sum(dy, 0, out=sink_b)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def sink_linear(x, weight, bias, sink_w, sink_b):
-    return _SinkLinear.apply(x, weight, bias, sink_w, sink_b)
+def sink_linear(x, weight, bias, sink_w, sink_b, collector=None, key=None):
+    return _SinkLinear.apply(x, weight, bias, sink_w, sink_b, collector, key)
 
 
 class _BceLoglik(torch.autograd.Function):

@@ -132,3 +132,57 @@ def test_a_rank_without_a_gpu_of_its_own_fails_with_a_clear_message(tmp_path):
         return
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "needs GPU 1" in out.stderr, out.stderr[-2000:]
+
+
+_LOWRANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["SVAE_ROOT"])
+import torch, torch.distributed as dist
+from spatial_vae_amd import dp
+rank, world, _ = dp.init_process_group(device_is_gpu=False)
+g = torch.Generator().manual_seed(7)
+rows_of = [[3, 2], [1, 0], [4, 4]]                    # per step: rows on rank 0, rank 1 (ragged; rank 1 EMPTY in step 2)
+w0, b0 = torch.full((6, 11), 9.0), torch.full((6,), 9.0)      # the sinks: views of the flat gradient buffer in TrainStep
+w1, b1 = torch.full((4, 6), 9.0), torch.full((4,), 9.0)
+ex = dp.LowRankExchange([("layers.0", w0, b0), ("layers.2", w1, b1)], torch.device("cpu"))
+assert ex.has("layers.0") and not ex.has("layers.4")
+for rows in rows_of:
+    xs = [(torch.randn(r, 11, generator=g), torch.randn(r, 6, generator=g), torch.randn(r, 6, generator=g),
+           torch.randn(r, 4, generator=g)) for r in rows]              # every rank draws every rank's factors: same stream
+    mine = xs[rank]
+    if rows[rank] > 0:
+        ex.add("layers.0", mine[0], mine[1])
+        ex.add("layers.2", mine[2], mine[3])
+    cap = (sum(rows) + world - 1) // world
+    cap = max(cap, max(rows))                          # the caller's shards are contiguous near-equal slices; here ragged on purpose
+    ex.start(cap).wait()
+    ex.finish()
+    want_w0 = sum(dy.t() @ x for x, dy, _, _ in xs)
+    want_w1 = sum(dy.t() @ x for _, _, x, dy in xs)
+    assert torch.allclose(w0, want_w0, atol=1e-5), (w0 - want_w0).abs().max()
+    assert torch.allclose(w1, want_w1, atol=1e-5)
+    assert torch.allclose(b0, sum(dy.sum(0) for _, dy, _, _ in xs), atol=1e-5)
+    assert torch.allclose(b1, sum(dy.sum(0) for _, _, _, dy in xs), atol=1e-5)
+    both = [torch.empty_like(w0) for _ in range(world)]
+    dist.all_gather(both, w0)
+    assert torch.equal(both[0], both[1]), "replicas must be bit-equal: every rank multiplies the same gathered factors"
+    assert ex.bytes_last == world * cap * (11 + 6 + 6 + 4) * 4
+print("rank", rank, "lowrank ok")
+dist.destroy_process_group()
+'''
+
+
+def test_low_rank_exchange_forms_the_global_weight_gradient(tmp_path):
+    """dp.LowRankExchange (the galaxy encoder's 983 MB first-layer gradient never crosses the wire): two gloo ranks with ragged
+    and EMPTY shards all-gather the factors of two layers' weight gradients and must each end up with the exact global
+    dW = sum_r dy_r^T x_r and db, bit-equal between the ranks."""
+    script = tmp_path / "lowrank_worker.py"
+    script.write_text(_LOWRANK_WORKER)
+    env = dict(os.environ, SVAE_ROOT=ROOT, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
+            "sys.exit(dp.launch_ranks(2, [%r]))" % (ROOT, str(script)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("lowrank ok") == 2

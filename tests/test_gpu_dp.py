@@ -17,9 +17,12 @@ import contextlib, io, math, os, sys
 sys.path.insert(0, os.environ["SVAE_ROOT"])
 import numpy as np, torch, torch.nn as nn, torch.distributed as dist
 import spatial_vae.models as models
-from spatial_vae_amd import dp, elbo as E, cli
+from spatial_vae_amd import dp, elbo as E, cli, ops
 
 out_path = os.environ["SVAE_DP_REF"]
+lowrank = os.environ.get("SVAE_TEST_LOWRANK") == "1"
+if lowrank:      # treat every encoder layer above 1000 weights as "large": 32 x 144 and 32 x 32 then take ops.sink_linear
+    ops.ENC_LINEAR_MAX_WEIGHT = 1000
 rank, world, local = dp.init_process_group(device_is_gpu=True)
 dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
@@ -32,6 +35,19 @@ bucketed = os.environ.get("SVAE_TEST_BUCKETED") == "1"
 step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=1e-2, bucketed=bucketed if world > 1 else None, rotate=True,
                     translate=True, dx_scale=0.1, theta_prior=math.pi / 4)
 assert step._bucketed == (bucketed and world > 1) and step.aliased()      # small encoder: one bucket unless asked otherwise
+finished = [0]
+if lowrank and world > 1:
+    # the two "large" layers exchange the factors of their weight gradients; their ranges are not all-reduced
+    assert step._lowrank is not None and step._lowrank.keys == {"layers.0", "layers.2"}
+    skipped = step.grads.buffer.numel() - sum(hi - lo for lo, hi in step.allreduce_segments())
+    assert skipped >= 32 * 144 + 32 + 32 * 32 + 32, skipped
+    orig_finish = step._lowrank.finish
+    def counting_finish():
+        finished[0] += 1
+        return orig_finish()
+    step._lowrank.finish = counting_finish
+else:
+    assert step._lowrank is None
 seed = dp.shared_seed(dev)
 x = cli.coord_grid(n, m).to(dev)
 rs = np.random.RandomState(7)
@@ -47,9 +63,10 @@ def bounds(i, b):
 metrics = []
 for i, (y, r) in enumerate(zip(ys, rs_)):
     lo, hi = bounds(i, y.size(0))
-    step(x, y[lo:hi], weight=(hi - lo) / y.size(0), noise=r[lo:hi])
+    step(x, y[lo:hi], weight=(hi - lo) / y.size(0), global_batch=y.size(0), noise=r[lo:hi])
     metrics.append(step.metrics.clone())
 torch.cuda.synchronize()
+assert finished[0] == (len(sizes) if (lowrank and world > 1) else 0)       # the low-rank path really ran, every step
 flat = step.grads.flat_param.detach().cpu()
 met = torch.stack(metrics).cpu()
 assert step.aliased()
@@ -69,15 +86,20 @@ else:
 '''
 
 
-@pytest.mark.parametrize("bucketed", [False, True], ids=["one_bucket", "two_buckets"])
-def test_two_ranks_on_one_gpu_match_the_single_rank_run(tmp_path, bucketed):
+@pytest.mark.parametrize("bucketed,lowrank", [(False, False), (True, False), (True, True), (False, True)],
+                         ids=["one_bucket", "two_buckets", "two_buckets_lowrank", "one_bucket_lowrank"])
+def test_two_ranks_on_one_gpu_match_the_single_rank_run(tmp_path, bucketed, lowrank):
     """Both collective schemes: ONE all-reduce after backward() (the default for small encoders) and the two-bucket form whose
-    first all-reduce is launched from inside backward() on a side stream (the default for the galaxy encoder)."""
+    first all-reduce is launched from inside backward() on a side stream (the default for the galaxy encoder) -- and each of
+    them with the large-layer path of the galaxy configuration: the encoder layers above the size limit all-gather the
+    factors (x, dy) of their weight gradients and form the global dW locally instead of all-reducing it (dp.LowRankExchange;
+    the limit is lowered in the worker so that a small encoder takes it), asserted taken on every step including the one
+    where rank 1 has no rows."""
     script = tmp_path / "dp_gpu_worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, SVAE_ROOT=ROOT, SVAE_DP_REF=str(tmp_path / "ref.pt"), PYTHONPATH=ROOT,
-               SVAE_TEST_BUCKETED="1" if bucketed else "0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU", "SVAE_DP_BUCKETS"):
+               SVAE_TEST_BUCKETED="1" if bucketed else "0", SVAE_TEST_LOWRANK="1" if lowrank else "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SVAE_SHARE_GPU", "SVAE_DP_BUCKETS", "SVAE_DP_LOWRANK"):
         env.pop(k, None)
     one = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-1500:] + one.stderr[-3000:]
