@@ -344,13 +344,15 @@ SEEDED_CASES = [
     dict(name="seeded_galaxy", script="galaxy", seed=77, count=48, n=32, m=32, channels=3, z_dim=4, H=32, q_hidden=32, L=3,
          q_layers=1, bs=20, epochs=2, lr=1e-3, save_interval=1, theta_prior=np.pi, dx_scale=0.1, z_delay=1, augment=True,
          argv=["x", "y", "--synthetic", "48", "--num_epochs", "2", "--minibatch_size", "20", "-z", "4", "--p_hidden_dim", "32",
-               "--q_hidden_dim", "32", "--p_num_layers", "3", "-l", "1e-3", "--z_delay", "1", "--augment_rotation",
+               "--q_hidden_dim", "32", "--p_num_layers", "3", "--q_num_layers", "1", "-l", "1e-3", "--z_delay", "1",
+               "--augment_rotation",
                "--save_prefix", "s", "--save_interval", "1", "--progress_every", "0", "--seed", "77"]),
     dict(name="seeded_particles", script="particles", seed=4321, count=96, n=40, m=40, channels=1, z_dim=3, H=48, q_hidden=32,
          L=2, q_layers=1, bs=40, epochs=2, lr=1e-3, save_interval=10, theta_prior=np.pi, dx_scale=0.1, z_delay=1, augment=False,
          fit_noise=True,
          argv=["x", "y", "--synthetic", "96", "--num-epochs", "2", "--minibatch-size", "40", "-z", "3", "--p-hidden-dim", "48",
-               "--q-hidden-dim", "32", "--p-num-layers", "2", "-l", "1e-3", "--z-delay", "1", "--fit-noise", "--progress-every",
+               "--q-hidden-dim", "32", "--p-num-layers", "2", "--q-num-layers", "1", "-l", "1e-3", "--z-delay", "1", "--fit-noise",
+               "--progress-every",
                "0", "--seed", "4321"]),
 ]
 SEEDED_CASES_BY_NAME = {c["name"]: c for c in SEEDED_CASES}
