@@ -64,6 +64,7 @@ struct Plan {
     float* dcoords;
     float* sgtile;  // fused first-layer backward: per-tile sums (tiles x 2 x Hp x 4)
     float* dfpart;  // fused first-layer backward: per-column-block d(coords) (ntile x Mp x 2)
+    float* llpart;  // fused Bernoulli finish: per-(image, pixel chunk) partial log-likelihoods (B x kFinishMaxChunks)
     uint4* splitA;  // fp16x3 mode: the row operand as hi/lo half fragments (Mp x Hp x 4 bytes)
     uint4* splitW;  // fp16x3 mode: one layer's weights as hi/lo half fragments
     uint4* savedC;    // fp16x3 mode, in `saved`: column fragments of a0 written by the coordinate layer (L == 2)
@@ -172,6 +173,13 @@ long recorded_plan(const void* saved) {
     return it == g_plans.end() ? -1L : (long)it->second.bits;
 }
 
+// pixel chunks per image of logits_finish_bce_kernel: 1024 pixels per block, at most kFinishMaxChunks blocks per image
+constexpr int kFinishMaxChunks = 64;
+int finish_chunks(int N) {
+    int c = (N + 1023) / 1024;
+    return c < 1 ? 1 : (c > kFinishMaxChunks ? kFinishMaxChunks : c);
+}
+
 Plan make_plan(const Geo& g, void* saved, void* ws) {
     Plan p;
     const size_t MH = (size_t)g.Mp * g.Hp;
@@ -248,6 +256,7 @@ Plan make_plan(const Geo& g, void* saved, void* ws) {
     p.dcoords = cw.take<float>((size_t)g.B * g.N * 2);
     p.sgtile = cw.take<float>((size_t)g.tiles * 2 * g.Hp * 4);
     p.dfpart = cw.take<float>((size_t)g.ntile * g.Mp * 2);
+    p.llpart = cw.take<float>((size_t)g.B * kFinishMaxChunks);
     p.splitA = p.splitW = nullptr;
     p.splitC[0] = p.splitC[1] = nullptr;
     p.hbpart = nullptr;
@@ -413,14 +422,9 @@ void launch_dense_ntr(const DenseArgs& a, dim3 grid, hipStream_t st) {
 template <int NT, bool DGRAD>
 void launch_dense_nt(const DenseArgs& a, dim3 grid, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
     if constexpr (!DGRAD && NT <= 4) {  // forward of the last hidden layer with the output layer's logits in the epilogue
-        if (cf == 1) {
+        if (cf >= 1) {                  // any channel count (a.C): the kernel takes CF as a flag
             if (a.resid) launch_dense_ntr<NT, false, true, false, 0, 1>(a, grid, st);
             else launch_dense_ntr<NT, false, false, false, 0, 1>(a, grid, st);
-            return;
-        }
-        if (cf == 2) {
-            if (a.resid) launch_dense_ntr<NT, false, true, false, 0, 2>(a, grid, st);
-            else launch_dense_ntr<NT, false, false, false, 0, 2>(a, grid, st);
             return;
         }
     }
@@ -771,9 +775,12 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
     }
 
     // the output layer's logits come out of the last hidden layer's epilogue (no second pass over a_{L-1}) whenever that
-    // layer is a dense_kernel launch and C <= 2; SVAE_FUSE_LOGITS=0 keeps the separate out_fwd pass
+    // layer is a dense_kernel launch; SVAE_FUSE_LOGITS=0 keeps the separate out_fwd pass.  The per-column-block partials
+    // [nblk][C][Mp] live in the (forward-idle) dfpart area of ntile * 2 * Mp floats: C <= 2 NT; the fp16x3 kernels carry
+    // at most two channels.
     static const bool fuse_env = [] { const char* e = getenv("SVAE_FUSE_LOGITS"); return !(e && e[0] == '0'); }();
-    const bool fuse_logits = fuse_env && g.L >= 2 && g.C <= 2;
+    const bool split_fwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0;
+    const bool fuse_logits = fuse_env && g.L >= 2 && (split_fwd ? g.C <= 2 : g.C <= 2 * dense_nt_first(g.ntile));
 
     launch_prepare(g, pl, p, pa, z, st);
     // fp16x3: bounded operands only, contraction length a multiple of 64
@@ -817,9 +824,16 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
         const int nblk = g.ntile / (split ? split_nt_fwd(g) : dense_nt_first(g.ntile));
-        if (bce_target)
-            hipLaunchKernelGGL(logits_finish_bce_kernel, dim3(g.B), dim3(g.N > 512 ? 1024 : (g.N > 256 ? 512 : 256)), 0, st, pl.dfpart, p->out_b, bce_target, y, logits,
-                               loglik, dll_dy, row_geo(g), g.C, nblk, (long)g.Mp);
+        if (bce_target) {
+            // one block per (image, chunk of <= 1024 pixels); with several chunks per image (galaxy: 16 384 pixels) their
+            // sums go to llpart and are added in chunk order by loglik_reduce_kernel (fixed order, no atomics)
+            const int chunks = finish_chunks(g.N);
+            hipLaunchKernelGGL(logits_finish_bce_kernel, dim3(g.B, chunks), dim3(g.N > 512 ? 1024 : (g.N > 256 ? 512 : 256)), 0, st,
+                               pl.dfpart, p->out_b, bce_target, y, logits, chunks > 1 ? pl.llpart : loglik, dll_dy, row_geo(g), g.C,
+                               nblk, (long)g.Mp);
+            if (chunks > 1)
+                hipLaunchKernelGGL(loglik_reduce_kernel, dim3(blocks_for(g.B)), dim3(256), 0, st, pl.llpart, loglik, g.B, chunks);
+        }
         else
             hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
                                logits, row_geo(g), g.C, nblk, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);

@@ -62,8 +62,8 @@ struct DenseArgs {
     const float* do_p;   // [C][Mp] d(loss)/d(logits), zero on pad rows
     const float* out_w;  // (C, H)
     int C;
-    // CF (forward of the LAST hidden layer, C <= 2): the epilogue also contracts its activations with W_o over this
-    // workgroup's columns -- the output layer's logits, one partial per column block, so a_{L-1} is not re-read
+    // CF (forward of the LAST hidden layer, any C <= SVAE_MAX_OUT): the epilogue also contracts its activations with W_o over
+    // this workgroup's columns -- the output layer's logits, one partial per column block, so a_{L-1} is not re-read
     float* lpart;        // [Hp/NB][C][Mp]
 };
 
@@ -196,7 +196,7 @@ struct DenseOcc {
 template <int NT, bool DGRAD, bool RESID, bool FIRST = false, int LASTD = 0, int CF = 0>
 __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOcc<NT, (FIRST || LASTD != 0)>::value)) void dense_kernel(DenseArgs a) {
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
-    static_assert(CF == 0 || (!DGRAD && CF <= 2), "CF is a forward epilogue for at most two output channels");
+    static_assert(CF == 0 || (!DGRAD && CF == 1), "CF is a forward epilogue (a flag: the channel count is a.C)");
     static_assert(LASTD == 0 || (DGRAD && !RESID), "LASTD is a data-gradient prologue without residual");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using Cfg = DenseCfg<NT>;
@@ -415,21 +415,6 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                     const float bv = DGRAD ? 0.0f : a.bias[n < a.H ? n : a.H - 1];
                     bias[t] = (n < a.H) ? bv : 0.0f;
                 }
-                constexpr int CFN = CF > 0 ? CF : 1;
-                float wo[CFN][NT], lp[CFN][16];  // CF: this lane's W_o entries and its rows' partial logits
-                if (CF > 0) {
-#pragma unroll
-                    for (int c = 0; c < CFN; ++c) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const int n = nb * NB + t * 32 + nl;
-                            const float wv = a.out_w[c * a.H + (n < a.H ? n : a.H - 1)];
-                            wo[c][t] = (n < a.H) ? wv : 0.0f;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) lp[c][r] = 0.0f;
-                    }
-                }
                 float4 dq[4];  // rank-1 forms: d(loss)/d(logit) of this lane's rows 8q + 4h .. +3 (zero on pad rows)
                 if (LASTD >= 2) {
 #pragma unroll
@@ -456,12 +441,8 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                         v = dense_epilogue<ACT, DGRAD>(v, bias[t], fa[q]);
                         if (LASTD >= 2) { v.x *= dq[q].x; v.y *= dq[q].y; v.z *= dq[q].z; v.w *= dq[q].w; }
                         *reinterpret_cast<float4*>(a.out + off0 + q * qstride + (long)t * 32 * 8) = v;
-                        if (CF > 0) {
-#pragma unroll
-                            for (int c = 0; c < CFN; ++c) {
-                                lp[c][4 * q] += v.x * wo[c][t]; lp[c][4 * q + 1] += v.y * wo[c][t];
-                                lp[c][4 * q + 2] += v.z * wo[c][t]; lp[c][4 * q + 3] += v.w * wo[c][t];
-                            }
+                        if (CF > 0) {  // the activations stay in the accumulator registers for the contraction with W_o below
+                            acc[t][4 * q] = v.x; acc[t][4 * q + 1] = v.y; acc[t][4 * q + 2] = v.z; acc[t][4 * q + 3] = v.w;
                         }
                     }
                 };
@@ -472,14 +453,29 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                         if ((DGRAD || RESID) && t + 1 < NT) fetch(t + 1, xa[(t + 1) & 1], xr[(t + 1) & 1]);
                         finish(t, xa[t & 1], xr[t & 1]);
                     }
-                    if (CF > 0) {  // sum over this block's columns (the 32 lanes of each half-wave); lanes nl < 4 store
+                    if (CF > 0) {
+                        // partial logits of this block's columns, one output channel at a time (a.C is wave-uniform): 16 + NT
+                        // registers whatever the channel count.  Per row the products are summed over the column tiles in
+                        // the order t = 0 .. NT-1, then over the 32 lanes of each half-wave; lanes nl < 4 store.
+                        for (int c = 0; c < a.C; ++c) {
+                            float wo[NT], lp[16];
 #pragma unroll
-                        for (int c = 0; c < CFN; ++c) {
+                            for (int t = 0; t < NT; ++t) {
+                                const int n = nb * NB + t * 32 + nl;
+                                const float wv = a.out_w[c * a.H + (n < a.H ? n : a.H - 1)];
+                                wo[t] = (n < a.H) ? wv : 0.0f;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) lp[r] = 0.0f;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) lp[r] += acc[t][r] * wo[t];
                             float s4[4];
-                            half_reduce16(lp[c], s4);
+                            half_reduce16(lp, s4);
                             if (nl < 4) {  // lane class -> row quad q; rows 8q + 4h .. +3 of the tile are consecutive
                                 const int q = ((nl & 1) << 1) | (nl >> 1);
-                                *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
+                                *reinterpret_cast<float4*>(a.lpart + ((long)nb * a.C + c) * a.Mp + tl * 32 + 8 * q + 4 * h) =
                                     make_float4(s4[0], s4[1], s4[2], s4[3]);
                             }
                         }

@@ -214,7 +214,11 @@ __global__ void __launch_bounds__(1024) logits_finish_bce_kernel(const float* __
     __shared__ float red[16];
     const int b = blockIdx.x;
     float acc = 0.0f;
-    for (int i = threadIdx.x; i < g.N; i += blockDim.x) {   // 1024 threads: one pixel each at 28 x 28 (a single round trip)
+    // gridDim.y chunks of the image's pixels (1 at 28 x 28 and 40 x 40: one pixel per thread, a single round trip; 16 at
+    // 128 x 128); with several chunks `loglik` is the [B][gridDim.y] partial array that loglik_reduce_kernel sums
+    const int per = (g.N + gridDim.y - 1) / gridDim.y;
+    const int i0 = blockIdx.y * per, i1 = (i0 + per < g.N) ? i0 + per : g.N;
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const long m = (long)b * g.Npad + i;
         const long t = (long)b * g.N + i;
         for (int c = 0; c < C; ++c) {
@@ -232,7 +236,16 @@ __global__ void __launch_bounds__(1024) logits_finish_bce_kernel(const float* __
         }
     }
     acc = block_sum_waves(acc, red);
-    if (threadIdx.x == 0) loglik[b] = acc;
+    if (threadIdx.x == 0) loglik[(long)b * gridDim.y + blockIdx.y] = acc;
+}
+
+// loglik[b] = sum over the pixel chunks of part[b][chunk], in chunk order
+__global__ void loglik_reduce_kernel(const float* __restrict__ part, float* __restrict__ loglik, int B, int chunks) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.0f;
+    for (int k = 0; k < chunks; ++k) s += part[(long)b * chunks + k];
+    loglik[b] = s;
 }
 
 // ---------------------------------------------------------------- output layer, backward, step 1
