@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "dense.h"
+#include "dense4.h"
 #include "elementwise.h"
 #include "encoder.h"
 #include "split.h"
@@ -321,10 +322,10 @@ static_assert(K_COUNT <= SVAE_PROF_KINDS, "svae_profile_read arrays too small");
 // geometry (fp16x3 falls back to the fp32 kernels for unbounded activations and odd tile counts), and a test must be able
 // to tell a run of the split kernels from a silent fallback
 enum Path { P_DENSE_FP32_FWD = 0, P_DENSE_FP32_DGRAD, P_WGRAD_FP32, P_DENSE_SPLIT_FWD, P_DENSE_SPLIT_DGRAD, P_WGRAD_SPLIT,
-            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_COUNT };
+            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_DENSE4, P_COUNT };
 const char* const kPathNames[SVAE_PATH_KINDS] = {"dense_fp32_fwd", "dense_fp32_dgrad", "wgrad_fp32", "dense_split_fwd",
                                                   "dense_split_dgrad", "wgrad_split", "out_bwd_stream", "out_bwd_split",
-                                                  "out_bwd_rank1", "out_bwd_fused_generic", "", "", "", "", "", ""};
+                                                  "out_bwd_rank1", "out_bwd_fused_generic", "dense4", "", "", "", "", ""};
 static_assert(P_COUNT <= SVAE_PATH_KINDS, "svae_path_counts array too small");
 std::atomic<long long> g_path[SVAE_PATH_KINDS];
 inline void took(int path) { g_path[path].fetch_add(1, std::memory_order_relaxed); }
@@ -632,11 +633,52 @@ void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const flo
     else hipLaunchKernelGGL(split_wgrad_kernel<true>, grid, dim3(256), kSplitWgradLds, st, w);
 }
 
+// dense4_kernel (four row tiles per wave, NT = 2 column tiles: dense4.h) takes a hidden-layer GEMM when the row space is
+// whole 128-row groups, the width whole 64-column blocks, there is no residual and no generic (LASTD == 1) output-layer form,
+// and the launch is large enough for its coarser work quantum (128 rows x 64 columns x K per wave; measured, dense4.h):
+// at least four rounds of the 512 resident workgroups.  SVAE_DENSE4=0 never, =1 whenever legal.
+bool use_dense4(const Geo& g, int resid, int lastd) {
+    const char* e = getenv("SVAE_DENSE4");  // read per call, like SVAE_FUSE_OUT: a test can compare both kernels in one process
+    const int mode = e ? (e[0] == '0' ? 0 : 1) : 2;
+    if (mode == 0 || g.tiles % 4 != 0 || g.ntile % 2 != 0 || resid || lastd == 1) return false;
+    const long wgs = ((g.tiles / 4 + 3) / 4) * (g.ntile / 2);
+    return mode == 1 || wgs >= 2048;
+}
+
+template <bool DGRAD, bool FIRST, int LASTD, int CF>
+void launch_dense4_v(const DenseArgs& a, long groups, hipStream_t st) {
+    constexpr int NT = 2;
+    const long sets = (groups + 3) / 4;
+    const dim3 grid((unsigned)(((sets + 7) / 8) * 8 * ((a.Hp / 32) / NT)));
+    hipLaunchKernelGGL((dense4_kernel<NT, DGRAD, FIRST, LASTD, CF>), grid, dim3(256), DenseCfg<NT>::LDS_BYTES, st, a, groups);
+}
+
+// returns the number of column tiles per workgroup the launch used (its partial results -- a.lpart, a.dfpart -- come per
+// column block of 32 x that many columns)
 template <bool DGRAD>
-void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
+int launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
     took(DGRAD ? P_DENSE_FP32_DGRAD : P_DENSE_FP32_FWD);
     if (lastd) took(lastd == 1 ? P_OUT_BWD_FUSED_GENERIC : P_OUT_BWD_RANK1);
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
+    if (use_dense4(g, a.resid, lastd)) {
+        took(P_DENSE4);
+        const long groups = g.tiles / 4;
+        if constexpr (!DGRAD) {
+            if (cf) launch_dense4_v<false, false, 0, 1>(a, groups, st);
+            else launch_dense4_v<false, false, 0, 0>(a, groups, st);
+        } else {
+            if (first) {
+                if (lastd == 2) launch_dense4_v<true, true, 2, 0>(a, groups, st);
+                else if (lastd == 3) launch_dense4_v<true, true, 3, 0>(a, groups, st);
+                else launch_dense4_v<true, true, 0, 0>(a, groups, st);
+            } else {
+                if (lastd == 2) launch_dense4_v<true, false, 2, 0>(a, groups, st);
+                else if (lastd == 3) launch_dense4_v<true, false, 3, 0>(a, groups, st);
+                else launch_dense4_v<true, false, 0, 0>(a, groups, st);
+            }
+        }
+        return 2;
+    }
     const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
     const long groups = (g.tiles + 3) / 4;
@@ -649,6 +691,7 @@ void launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first =
         case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first, lastd, cf); break;
         default: launch_dense_nt<1, DGRAD>(a, grid, st, first, lastd, cf); break;
     }
+    return nt;
 }
 
 template <int CL, int R1 = 0>
@@ -778,9 +821,11 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
     // layer is a dense_kernel launch; SVAE_FUSE_LOGITS=0 keeps the separate out_fwd pass.  The per-column-block partials
     // [nblk][C][Mp] live in the (forward-idle) dfpart area of ntile * 2 * Mp floats: C <= 2 NT; the fp16x3 kernels carry
     // at most two channels.
-    static const bool fuse_env = [] { const char* e = getenv("SVAE_FUSE_LOGITS"); return !(e && e[0] == '0'); }();
+    const char* fuse_e = getenv("SVAE_FUSE_LOGITS");  // read per call (a test switches it)
+    const bool fuse_env = !(fuse_e && fuse_e[0] == '0');
     const bool split_fwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0;
-    const bool fuse_logits = fuse_env && g.L >= 2 && (split_fwd ? g.C <= 2 : g.C <= 2 * dense_nt_first(g.ntile));
+    const bool fuse_logits = fuse_env && g.L >= 2 &&
+                             (split_fwd ? g.C <= 2 : g.C <= 2 * (use_dense4(g, g.flags & SVAE_FLAG_RESID, 0) ? 2 : dense_nt_first(g.ntile)));
 
     launch_prepare(g, pl, p, pa, z, st);
     // fp16x3: bounded operands only, contraction length a multiple of 64
@@ -797,6 +842,7 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
             default: launch_layer0_fwd<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st); break;
         }
     }
+    int cf_nt = dense_nt_first(g.ntile);  // column tiles per block of the launch that wrote the partial logits
     for (int l = 1; l < g.L; ++l) {
         if (split) {
             launch_split_fwd(g, pl, pl.act[l - 1], p->hidden_w[l - 1], p->hidden_b[l - 1], pl.act[l],
@@ -819,11 +865,12 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
         a.do_p = nullptr; a.out_w = p->out_w; a.C = g.C;
         a.lpart = pl.dfpart;  // free during the forward pass; nblk * C * Mp <= ntile * 2 * Mp floats
-        launch_dense<false>(g, a, st, false, 0, (fuse_logits && l == g.L - 1) ? g.C : 0);
+        const int nt_used = launch_dense<false>(g, a, st, false, 0, (fuse_logits && l == g.L - 1) ? g.C : 0);
+        if (l == g.L - 1) cf_nt = nt_used;
     }
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
-        const int nblk = g.ntile / (split ? split_nt_fwd(g) : dense_nt_first(g.ntile));
+        const int nblk = g.ntile / (split ? split_nt_fwd(g) : cf_nt);
         if (bce_target) {
             // one block per (image, chunk of <= 1024 pixels); with several chunks per image (galaxy: 16 384 pixels) their
             // sums go to llpart and are added in chunk order by loglik_reduce_kernel (fixed order, no atomics)
@@ -942,6 +989,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
 
     // hidden layers, last to first
     bool fused_first = false;
+    int first_nt = dense_nt_first(g.ntile);  // column tiles per block of the fp32 launch that ran the FIRST epilogue
     for (int l = g.L - 1; l >= 1; --l) {
         const bool last = fused_out && l == g.L - 1;
         // fp16x3 runs down the stack: every split data gradient leaves the scale of its result for the layer below
@@ -1001,8 +1049,10 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
         if (split_here)
             launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa,
                                split_ob && l == g.L - 1, st);
-        else
-            launch_dense<true>(g, a, st, fused_first, last ? (r1 ? (g.act == SVAE_ACT_TANH ? 2 : 3) : 1) : 0);
+        else {
+            const int nt_used = launch_dense<true>(g, a, st, fused_first, last ? (r1 ? (g.act == SVAE_ACT_TANH ? 2 : 3) : 1) : 0);
+            if (l == 1) first_nt = nt_used;
+        }
         cur ^= 1;
     }
 
@@ -1019,7 +1069,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             hipLaunchKernelGGL(first_layer_image_kernel, dim3(g.B, want_coords ? 2 : 1), dim3(256), 0, st, pl.sgtile,
                                split_first ? 2 : 1, g.Timg, g.H, g.Hp, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr,
                                want_dz ? dz : (float*)nullptr, g.Zd, g.in_dim, pl.dfpart,
-                               g.ntile / (split_first ? split_nt(g) : dense_nt_first(g.ntile)), g.N, g.Npad, (long)g.Mp,
+                               g.ntile / (split_first ? split_nt(g) : first_nt), g.N, g.Npad, (long)g.Mp,
                                want_coords ? dc : (float*)nullptr, pose->grid, pl.posebuf, pg ? pg->dtheta : (float*)nullptr,
                                pg ? pg->ddx : (float*)nullptr);
         } else {

@@ -164,7 +164,7 @@ __device__ __forceinline__ void wait_vm_chunk(float (&v)[4][4]) {
 // Timing-only ablation switches for tools/dense_ablate.hip (never defined in the product build):
 //   1 = no epilogue   2 = no barrier / LDS-DMA in the loop   4 = no B-fragment reads in the loop
 //   8 = no A-operand loads in the loop   16 = half of the MFMAs   32 = every tile reads the rows of tile 0
-//   64 = LDS-DMA issued but never awaited and no barrier
+//   64 = LDS-DMA issued but never awaited and no barrier   128 = A-operand loads issued but never awaited in the loop
 #ifndef SVAE_ABLATE
 #define SVAE_ABLATE 0
 #endif
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, ((CF > 0 && NT <= 4) ? SVAE_CF_WAVES : DenseOc
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    wait_vm1<15 + P>(av[gl][e]);
+                    if (!(SVAE_ABLATE & 128)) wait_vm1<15 + P>(av[gl][e]);
                     // rank-1 forms: act'(a) in ONE fma -- tanh 1 - a^2 (LASTD == 2), sigmoid a - a^2 (LASTD == 3).  (Forming it
                     // one slot ahead, behind the previous MFMA group, was measured: no change -- the cost is the VALU
                     // instruction's share of the matrix pipe, ~13 cycles per slot, not the dependency.)
