@@ -650,7 +650,9 @@ void launch_dense4_v(const DenseArgs& a, long groups, hipStream_t st) {
     constexpr int NT = 2;
     const long sets = (groups + 3) / 4;
     const dim3 grid((unsigned)(((sets + 7) / 8) * 8 * ((a.Hp / 32) / NT)));
-    hipLaunchKernelGGL((dense4_kernel<NT, DGRAD, FIRST, LASTD, CF>), grid, dim3(256), DenseCfg<NT>::LDS_BYTES, st, a, groups);
+    // LDS: the two weight buffers, and for FIRST 3 x 128 floats per wave of per-row operands behind them
+    constexpr int lds = DenseCfg<NT>::LDS_BYTES + (FIRST ? 4 * 3 * 128 * 4 : 0);
+    hipLaunchKernelGGL((dense4_kernel<NT, DGRAD, FIRST, LASTD, CF>), grid, dim3(256), lds, st, a, groups);
 }
 
 // returns the number of column tiles per workgroup the launch used (its partial results -- a.lpart, a.dfpart -- come per
@@ -664,8 +666,13 @@ int launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = 
         took(P_DENSE4);
         const long groups = g.tiles / 4;
         if constexpr (!DGRAD) {
-            if (cf) launch_dense4_v<false, false, 0, 1>(a, groups, st);
-            else launch_dense4_v<false, false, 0, 0>(a, groups, st);
+            switch (cf) {
+                case 0: launch_dense4_v<false, false, 0, 0>(a, groups, st); break;
+                case 1: launch_dense4_v<false, false, 0, 1>(a, groups, st); break;
+                case 2: launch_dense4_v<false, false, 0, 2>(a, groups, st); break;
+                case 3: launch_dense4_v<false, false, 0, 3>(a, groups, st); break;
+                default: launch_dense4_v<false, false, 0, 4>(a, groups, st); break;
+            }
         } else {
             if (first) {
                 if (lastd == 2) launch_dense4_v<true, true, 2, 0>(a, groups, st);

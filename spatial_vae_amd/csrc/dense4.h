@@ -56,13 +56,13 @@ __device__ __forceinline__ f32x4v rank1_actgrad(f32x4v x) {
 //   DGRAD  data gradient: the epilogue multiplies by act'(aux)
 //   FIRST  (DGRAD) data gradient into the coordinate layer: reduce instead of store (dense_kernel's FIRST epilogue)
 //   LASTD  0, or 2 (tanh) / 3 (sigmoid): the rank-1 output-layer form (DGRAD): `in` is a_{L-1}, rows scaled by do[m] in the epilogue
-//   CF     forward of the last hidden layer: the epilogue also contracts with W_o (a.C channels) into a.lpart
+//   CF     forward of the last hidden layer: the epilogue also contracts with W_o (CF = a.C channels) into a.lpart
 template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
 __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups) {
     static_assert(NT == 1 || NT == 2, "4 NT accumulator tiles: two waves per SIMD up to NT = 2");
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(LASTD == 0 || ((LASTD == 2 || LASTD == 3) && DGRAD), "LASTD: the rank-1 data-gradient forms only");
-    static_assert(CF == 0 || (!DGRAD && CF == 1), "CF is a forward epilogue (a flag: the channel count is a.C)");
+    static_assert(CF == 0 || (!DGRAD && CF <= SVAE_MAX_OUT), "CF = output channels of the forward epilogue's W_o contraction");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using Cfg = DenseCfg<NT>;
     constexpr int NB = Cfg::NB, G = Cfg::G, CHUNK = Cfg::CHUNK, NINSTR = Cfg::NINSTR;
@@ -126,6 +126,26 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
     constexpr int PE = (P + 3) / 4;
     static_assert(G == 4, "the slot offsets assume 4 octets per chunk");
 
+    // FIRST: the posed coordinates (x0, x1) of this wave's 128 rows (0 on pad rows) and, for the rank-1 forms, their
+    // d(loss)/d(logit) go into a wave-private LDS area behind the weight buffers now, two rows per lane; the epilogue reads them
+    // back four rows at a time (wave-private: no barrier, the compiler's lgkmcnt waits order the write and the reads)
+    float* rowx = smem + 2 * CHUNK + wave * (3 * 128);  // [x0 | x1 | do] x 128 rows
+    if (FIRST) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = lane + 64 * rr;
+            const long tile = rgl * 4 + (row >> 5);
+            const int b = (int)(tile / a.Timg);
+            const int i = (int)(tile % a.Timg) * 32 + (row & 31);
+            const float4 pb = a.posebuf[b];  // identity (1, 0, 0, 0) when the coordinates are explicit
+            const float* cbase = a.pose.coords ? a.pose.coords + (long)b * a.N * 2 : a.pose.grid;
+            const float2 g2 = *reinterpret_cast<const float2*>(cbase + (long)(i < a.N ? i : a.N - 1) * 2);
+            const bool in = i < a.N;
+            rowx[row] = in ? pb.x * g2.x - pb.y * g2.y + pb.z : 0.0f;
+            rowx[128 + row] = in ? pb.y * g2.x + pb.x * g2.y + pb.w : 0.0f;
+            if (LASTD != 0) rowx[256 + row] = a.do_p[rgl * 128 + row];
+        }
+    }
     stage(0, 0);
     stage(nchunk > 1 ? 1 : 0, 1);
     f32x4v av[G][4];
@@ -210,8 +230,9 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
     if (!live) return;
 
     // ---- epilogue.  A "slab" s = q * NT + t is the 16 rows 32q + 16h + 4r + c (r, c = 0..3) of column n of tile t: four
-    // 16-byte vectors (one per r, the four tiles' registers 4q + r).  Loads of slab s+1 are issued before the stores of slab s
-    // (vmcnt counts stores too, in issue order).
+    // 16-byte vectors (one per r, the four tiles' registers 4q + r).  Everything is ordered tile by tile (q outermost), so the
+    // accumulator registers of a finished tile are dead and the per-tile state of the fused forms fits beside the rest:
+    // no spills (a spilled value costs a scratch round trip per use here, and the wave sits in its epilogue meanwhile).
     auto epi = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
         constexpr int NS = 4 * NT;
@@ -226,17 +247,6 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
         auto voff = [&](int q, int r, int t) -> long {
             return ((rgl * 16 + 4 * q + 2 * h + (r >> 1)) * (long)Hp + nb * NB + t * 32 + nl) * 8 + 4 * (r & 1);
         };
-        float4 xa[2][4];   // aux (a_{l-1}) of slab s / s+1
-        float4 dqv[2][4];  // rank-1 forms: d(loss)/d(logit) of the 16 rows of tile q / q+1 (zero on pad rows)
-        auto fetch_aux = [&](int s, float4 (&fa)[4]) {
-            const int q = s / NT, t = s % NT;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fa[r] = *reinterpret_cast<const float4*>(a.aux + voff(q, r, t));
-        };
-        auto fetch_dq = [&](int q, float4 (&d)[4]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = *reinterpret_cast<const float4*>(a.do_p + rgl * 128 + 32 * q + 16 * h + 4 * r);
-        };
         // vector (q, r) of tile t after the elementwise part of the epilogue
         auto value = [&](int q, int r, int t, const float4& aux, const float4& dq) -> float4 {
             float4 v = make_float4(acc[0][t][4 * q + r], acc[1][t][4 * q + r], acc[2][t][4 * q + r], acc[3][t][4 * q + r]);
@@ -245,52 +255,68 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
             return v;
         };
         if (!FIRST) {
-            if (DGRAD) fetch_aux(0, xa[0]);
-            if (LASTD != 0) fetch_dq(0, dqv[0]);
+            float4 xa[2][4];   // aux (a_{l-1}) of slab s / s+1: loads of slab s+1 are issued before the stores of slab s
+            float4 dqv[2][4];  // rank-1 forms: d(loss)/d(logit) of the 16 rows of tile q / q+1 (zero on pad rows)
+            auto fetch_aux = [&](int s_, float4 (&fa)[4]) {
+                const int q = s_ / NT, t = s_ % NT;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int q = s / NT, t = s % NT;
-                if (s + 1 < NS) {
-                    if (DGRAD) fetch_aux(s + 1, xa[(s + 1) & 1]);
-                    if (LASTD != 0 && (s + 1) % NT == 0) fetch_dq((s + 1) / NT, dqv[((s + 1) / NT) & 1]);
-                }
+                for (int r = 0; r < 4; ++r) fa[r] = *reinterpret_cast<const float4*>(a.aux + voff(q, r, t));
+            };
+            auto fetch_dq = [&](int q, float4 (&d)[4]) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 v = value(q, r, t, xa[s & 1][r], dqv[q & 1][r]);
-                    *reinterpret_cast<float4*>(a.out + voff(q, r, t)) = v;
-                    if (CF > 0) {  // the activations stay in the accumulator registers for the contraction with W_o below
-                        acc[0][t][4 * q + r] = v.x; acc[1][t][4 * q + r] = v.y; acc[2][t][4 * q + r] = v.z; acc[3][t][4 * q + r] = v.w;
-                    }
-                }
-            }
+                for (int r = 0; r < 4; ++r) d[r] = *reinterpret_cast<const float4*>(a.do_p + rgl * 128 + 32 * q + 16 * h + 4 * r);
+            };
+            // CF: this lane's W_o entries, and per channel the partial logits of the current tile's 16 rows
+            constexpr int CFN = CF > 0 ? CF : 1;
+            float wo[CFN][NT], lp[CFN][16];
             if (CF > 0) {
-                // partial logits of this block's columns: per output channel (a.C is wave-uniform) and 32-row tile q, the 16
-                // rows' products are summed over the column tiles in the order t = 0 .. NT-1, then over the 32 lanes of each
-                // half-wave (half_reduce16: lane class cls ends up with rows 16h + 4 cls .. +3 of the tile)
-                for (int c = 0; c < a.C; ++c) {
-                    float wo[NT];
+#pragma unroll
+                for (int c = 0; c < CFN; ++c)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int n = nb * NB + t * 32 + nl;
                         const float wv = a.out_w[c * a.H + (n < a.H ? n : a.H - 1)];
-                        wo[t] = (n < a.H) ? wv : 0.0f;
+                        wo[c][t] = (n < a.H) ? wv : 0.0f;
                     }
+            }
+            if (DGRAD) fetch_aux(0, xa[0]);
+            if (LASTD != 0) fetch_dq(0, dqv[0]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float lp[16];
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const int q = s_ / NT, t = s_ % NT;
+                if (s_ + 1 < NS) {
+                    if (DGRAD) fetch_aux(s_ + 1, xa[(s_ + 1) & 1]);
+                    if (LASTD != 0 && (s_ + 1) % NT == 0) fetch_dq((s_ + 1) / NT, dqv[((s_ + 1) / NT) & 1]);
+                }
+                if (CF > 0 && t == 0) {
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) lp[j] = 0.0f;
+                    for (int c = 0; c < CFN; ++c)
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
+                        for (int j = 0; j < 16; ++j) lp[c][j] = 0.0f;
+                }
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v = value(q, r, t, xa[s_ & 1][r], dqv[q & 1][r]);
+                    *reinterpret_cast<float4*>(a.out + voff(q, r, t)) = v;
+                    if (CF > 0) {
 #pragma unroll
-                                for (int cc = 0; cc < 4; ++cc) lp[4 * r + cc] += acc[cc][t][4 * q + r] * wo[t];
+                        for (int c = 0; c < CFN; ++c) {
+                            lp[c][4 * r] += v.x * wo[c][t]; lp[c][4 * r + 1] += v.y * wo[c][t];
+                            lp[c][4 * r + 2] += v.z * wo[c][t]; lp[c][4 * r + 3] += v.w * wo[c][t];
+                        }
+                    }
+                }
+                if (CF > 0 && t == NT - 1) {
+                    // partial logits of tile q over this block's columns: summed over the column tiles in the order t = 0 .. NT-1
+                    // (above), then over the 32 lanes of each half-wave (half_reduce16: lane class cls ends up with rows
+                    // 16h + 4 cls .. +3 of the tile)
+#pragma unroll
+                    for (int c = 0; c < CFN; ++c) {
                         float s4[4];
-                        half_reduce16(lp, s4);
+                        half_reduce16(lp[c], s4);
                         if (nl < 4) {
                             const int cls = ((nl & 1) << 1) | (nl >> 1);
-                            *reinterpret_cast<float4*>(a.lpart + ((long)nb * a.C + c) * a.Mp + rgl * 128 + 32 * q + 16 * h + 4 * cls) =
+                            *reinterpret_cast<float4*>(a.lpart + ((long)nb * CFN + c) * a.Mp + rgl * 128 + 32 * q + 16 * h + 4 * cls) =
                                 make_float4(s4[0], s4[1], s4[2], s4[3]);
                         }
                     }
@@ -298,70 +324,81 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
             }
         } else {
             // FIRST: dh0 is reduced on the spot (dense_kernel's FIRST epilogue, per actual tile q of the group): over the tile's
-            // rows into (G0, G1, S) per feature, over this block's features into d(coords) per row.
+            // rows into (G0, G1, S) per feature, over this block's features into d(coords) per row.  Each tile goes in two
+            // half passes of 8 rows per lane (rows 16h + 8 rh + j, j = 0..7 <-> r = 2 rh + j/4, c = j % 4), which halves the
+            // per-tile state and lets ONE half_reduce16 serve both coordinate components.  Per-row operands come from the
+            // LDS area staged in the prologue; the a_0 vectors of the next half pass are loaded before this one is computed.
+            float4 xa[2][NT][2];
+            auto fetch_aux = [&](int hp, float4 (&fa)[NT][2]) {
+                const int q = hp >> 1, rh = hp & 1;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) fa[t][r2] = *reinterpret_cast<const float4*>(a.aux + voff(q, 2 * rh + r2, t));
+            };
             fetch_aux(0, xa[0]);
-            if (LASTD != 0) fetch_dq(0, dqv[0]);
+            float2 w[NT];
+            float sv[NT], g0[NT], g1[NT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int hp = 0; hp < 8; ++hp) {
+                const int q = hp >> 1, rh = hp & 1;
                 const long tile = rgl * 4 + q;
-                const int b = (int)(tile / a.Timg);
-                const int i0 = (int)(tile % a.Timg) * 32 + 16 * h;  // this lane's rows of the image: i0 + 4r + c
-                const float4 pb = a.posebuf[b];  // identity (1, 0, 0, 0) when the coordinates are explicit
-                const float* cbase = a.pose.coords ? a.pose.coords + (long)b * a.N * 2 : a.pose.grid;
-                float2 raw[16];
-                float x0[16], x1[16], pd0[16], pd1[16];
+                if (rh == 0) {
+                    const int b = (int)(tile / a.Timg);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {  // 16 independent loads, no branches: pad rows re-read row N-1
-                    const int i = i0 + j;
-                    raw[j] = *reinterpret_cast<const float2*>(cbase + (long)(i < a.N ? i : a.N - 1) * 2);
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const bool in = i0 + j < a.N;
-                    x0[j] = in ? pb.x * raw[j].x - pb.y * raw[j].y + pb.z : 0.0f;
-                    x1[j] = in ? pb.y * raw[j].x + pb.x * raw[j].y + pb.w : 0.0f;
-                    pd0[j] = 0.0f; pd1[j] = 0.0f;
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int s = q * NT + t;
-                    const int k = nb * NB + t * 32 + nl;
-                    const float2 w = *reinterpret_cast<const float2*>(a.tab + ((long)b * Hp + k) * kSlots);
-                    if (s + 1 < NS) {
-                        fetch_aux(s + 1, xa[(s + 1) & 1]);
-                        if (LASTD != 0 && (s + 1) % NT == 0) fetch_dq((s + 1) / NT, dqv[((s + 1) / NT) & 1]);
+                    for (int t = 0; t < NT; ++t) {
+                        w[t] = *reinterpret_cast<const float2*>(a.tab + ((long)b * Hp + nb * NB + t * 32 + nl) * kSlots);
+                        sv[t] = 0.0f; g0[t] = 0.0f; g1[t] = 0.0f;
                     }
-                    float sv = 0.0f, g0 = 0.0f, g1 = 0.0f;
+                }
+                if (hp + 1 < 8) fetch_aux(hp + 1, xa[(hp + 1) & 1]);
+                const float* rx = rowx + 32 * q + 16 * h + 8 * rh;  // this lane's 8 rows of the group
+                float4 x0v[2], x1v[2], dq[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float4 v = value(q, r, t, xa[s & 1][r], dqv[q & 1][r]);
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    x0v[r2] = *reinterpret_cast<const float4*>(rx + 4 * r2);
+                    x1v[r2] = *reinterpret_cast<const float4*>(rx + 128 + 4 * r2);
+                    if (LASTD != 0) dq[r2] = *reinterpret_cast<const float4*>(rx + 256 + 4 * r2);
+                }
+                float pd[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pd[j] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const float4 v = value(q, 2 * rh + r2, t, xa[hp & 1][t][r2], dq[r2]);
                         const float vv[4] = {v.x, v.y, v.z, v.w};
+                        const float xx0[4] = {x0v[r2].x, x0v[r2].y, x0v[r2].z, x0v[r2].w};
+                        const float xx1[4] = {x1v[r2].x, x1v[r2].y, x1v[r2].z, x1v[r2].w};
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) {
-                            const int j = 4 * r + cc;
-                            sv += vv[cc];
-                            g0 += vv[cc] * x0[j];
-                            g1 += vv[cc] * x1[j];
-                            pd0[j] += vv[cc] * w.x;
-                            pd1[j] += vv[cc] * w.y;
+                            const int j = 4 * r2 + cc;
+                            sv[t] += vv[cc];
+                            g0[t] += vv[cc] * xx0[cc];
+                            g1[t] += vv[cc] * xx1[cc];
+                            pd[j] += vv[cc] * w[t].x;
+                            pd[8 + j] += vv[cc] * w[t].y;
                         }
                     }
-                    // the two half-waves hold the two row halves of the same (tile, feature): one sum
-                    g0 += __shfl_xor(g0, 32);
-                    g1 += __shfl_xor(g1, 32);
-                    sv += __shfl_xor(sv, 32);
-                    if (h == 0) *reinterpret_cast<float4*>(a.sgtile + (tile * (long)Hp + k) * 4) = make_float4(g0, g1, sv, 0.0f);
-                }
-                // d(coords) of each row: this block's NB features = over the tiles (done) and the 32 lanes
-                float s0[4], s1[4];
-                half_reduce16(pd0, s0);
-                half_reduce16(pd1, s1);
+                // d(coords) of the 8 rows: this block's NB features = over the tiles (done) and the 32 lanes of the half-wave;
+                // lane class cls ends up with values 4 cls .. 4 cls + 3: component cls / 2 of rows 4 (cls % 2) .. + 3
+                float s4[4];
+                half_reduce16(pd, s4);
                 if (nl < 4) {
                     const int cls = ((nl & 1) << 1) | (nl >> 1);
-                    const long m = tile * 32 + 16 * h + 4 * cls;
-                    float4* dst = reinterpret_cast<float4*>(a.dfpart + ((long)nb * a.Mp + m) * 2);
-                    dst[0] = make_float4(s0[0], s1[0], s0[1], s1[1]);
-                    dst[1] = make_float4(s0[2], s1[2], s0[3], s1[3]);
+                    float* dst = a.dfpart + ((long)nb * a.Mp + tile * 32 + 16 * h + 8 * rh + 4 * (cls & 1)) * 2 + (cls >> 1);
+                    dst[0] = s4[0]; dst[2] = s4[1]; dst[4] = s4[2]; dst[6] = s4[3];
+                }
+                if (rh == 1) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        // the two half-waves hold the two row halves of the same (tile, feature): one sum
+                        const float G0 = g0[t] + __shfl_xor(g0[t], 32), G1 = g1[t] + __shfl_xor(g1[t], 32);
+                        const float S = sv[t] + __shfl_xor(sv[t], 32);
+                        const int k = nb * NB + t * 32 + nl;
+                        if (h == 0) *reinterpret_cast<float4*>(a.sgtile + (tile * (long)Hp + k) * 4) = make_float4(G0, G1, S, 0.0f);
+                    }
                 }
             }
         }
