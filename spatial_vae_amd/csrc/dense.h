@@ -656,6 +656,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool own_bias = bj == 0 && (wave & 1) == 0;  // the waves whose bias partials are stored (see the end of the kernel)
 
     // Operands stream HBM/L2 -> LDS by LDS-DMA into a PRIVATE ring of this wave (4 slots x 8 pieces of
     // 1 KiB: dh tiles 0-3, a_prev tiles 0-3; lane l's 16 bytes at 16*l of a piece = conflict-free
@@ -674,15 +675,29 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     float* ring = smem + wave * (4 * kSlotFloats);
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
     const long ostride = (long)Hp * 8;
+    // The row octet is wave-uniform, so each piece is (scalar base of the octet) + (this lane's constant 32-bit byte offset):
+    // the 64-bit address of a piece costs two scalar adds instead of two VALU adds per lane (r03: 16-18 VALU instructions per
+    // octet gone from a loop in which every one of them takes matrix-pipe time).
+    unsigned voa[4], vob[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        voa[t] = (unsigned)((pa[t] - a.dh) * 4);
+        vob[t] = (unsigned)((pb[t] - a.aprev) * 4);
+    }
+    const unsigned vod = (unsigned)(((lane >> 1) < 1 ? (lane & 1) : 0) * 16);  // CL == 1: lanes 0, 1 fetch do_p[8 oc + 4 hh .. +3]
     auto dma = [&](long o) {
         const long oc = (o < o1) ? o : o1 - 1;
         const long off = oc * ostride;
         const unsigned slot = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((o - o0) & 3) * (kSlotFloats * 4u));
+        const float* ba = a.dh + off;
+        const float* bb = a.aprev + off;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(pa[t] + off, slot + t * 1024u);
+        for (int t = 0; t < 4; ++t) glds16_s(ba, voa[t], slot + t * 1024u);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(pb[t] + off, slot + (4 + t) * 1024u);
-        if (CL > 0) {
+        for (int t = 0; t < 4; ++t) glds16_s(bb, vob[t], slot + (4 + t) * 1024u);
+        if (CL == 1) {
+            glds16_s(a.do_p + oc * 8, vod, slot + 8 * 1024u);
+        } else if (CL > 1) {
             // lane (2c + hh) fetches do_p[c][8*oc + 4*hh .. +3]; the other lanes re-fetch lane 0's 16 bytes
             const int c = (lane >> 1) < CL ? (lane >> 1) : 0, hh = (lane >> 1) < CL ? (lane & 1) : 0;
             glds16(a.do_p + (long)c * a.Mp + oc * 8 + 4 * hh, slot + 8 * 1024u);
@@ -791,8 +806,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i].w, xb[j].w, acc[i][j], 0, 0, 0);
+        if (own_bias) {  // wave-uniform: only the waves that store bslab sum the columns of dh (12 VALU instructions per octet)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bs[t] += (xa[t].x + xa[t].y) + (xa[t].z + xa[t].w);
+            for (int t = 0; t < 4; ++t) bs[t] += (xa[t].x + xa[t].y) + (xa[t].z + xa[t].w);
+        }
     };
     if (o0 < o1) {
         float4 ca[4], cb[4], na[4], nb[4];
@@ -851,7 +868,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
             if (bi == 0 && wave == 0 && nl == 0) a.bpart[((long)split * 2 + h) * CL + c] = pbias[c];
         }
     }
-    if (bj == 0 && (wave & 1) == 0) {
+    if (own_bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (ibase + i < ntile) a.bslab[((long)split * 2 + h) * Hp + (ibase + i) * 32 + nl] = bs[i];
