@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _LIB = os.path.join(_HERE, "libsvae_hip.so")
-_SOURCES = ("api.hip", "common.h", "dense.h", "elementwise.h", "encoder.h", "split.h")
+_SOURCES = tuple(sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))))   # every file api.hip may include
 
 
 def library_path():

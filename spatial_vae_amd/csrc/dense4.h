@@ -165,33 +165,38 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
     __syncthreads();  // chunks 0 and 1 have landed in LDS
     read_b(0, b0);
     const int spare = nchunk & 1;  // buffer that held chunk nchunk-2: the sink of redundant re-stages
-    for (int c = 0; c < nchunk; ++c) {
-        const float* anext = arow + (long)(c + 1 < nchunk ? c + 1 : nchunk - 1) * (G * 64);
+    // one k-step: the four row tiles x NT column tiles that share this A vector and these B values
+    auto kstep = [&](const f32x4v& a4, const float4 (&bf)[NT], int e) {
+        const f32x4v x = LASTD != 0 ? rank1_actgrad<LASTD>(a4) : a4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float bv = e == 0 ? bf[t].x : e == 1 ? bf[t].y : e == 2 ? bf[t].z : bf[t].w;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[0], bv, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[1], bv, acc[1][t], 0, 0, 0);
+            acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[2], bv, acc[2][t], 0, 0, 0);
+            acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[3], bv, acc[3][t], 0, 0, 0);
+        }
+    };
+    // all chunks but the last: MFMAs of chunk c, A loads of chunk c+1, DMA of chunk c+2
+    for (int c = 0; c + 1 < nchunk; ++c) {
+        const float* anext = arow + (long)(c + 1) * (G * 64);
         const bool more = c + 2 < nchunk;
         const int cstage = more ? c + 2 : nchunk - 1, bstage = more ? (c & 1) : spare;
 #pragma unroll
         for (int gl = 0; gl < G; ++gl) {
             const int o = c * G + gl;
             if (gl == G - 1) {
+                // the next octet opens chunk c+1: its DMA must have landed in every wave's view, and every wave must hold its
+                // last fragments of chunk c before that buffer is reused
                 wait_vm4<12>(av[gl][0]);
                 __syncthreads();
             }
-            const int onext = (o + 1 < noct) ? o + 1 : noct - 1;
-            if (gl & 1) read_b(onext, b0); else read_b(onext, b1);
+            if (gl & 1) read_b(o + 1, b0); else read_b(o + 1, b1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 wait_vm4<15 + P>(av[gl][e]);
-                const f32x4v x = LASTD != 0 ? rank1_actgrad<LASTD>(av[gl][e]) : av[gl][e];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float4 bb = (gl & 1) ? b1[t] : b0[t];
-                    const float bv = e == 0 ? bb.x : e == 1 ? bb.y : e == 2 ? bb.z : bb.w;
-                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[0], bv, acc[0][t], 0, 0, 0);
-                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[1], bv, acc[1][t], 0, 0, 0);
-                    acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[2], bv, acc[2][t], 0, 0, 0);
-                    acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[3], bv, acc[3][t], 0, 0, 0);
-                }
+                if (gl & 1) kstep(av[gl][e], b1, e); else kstep(av[gl][e], b0, e);
                 __builtin_amdgcn_sched_barrier(0);
                 // re-issue this register quad's load for the next chunk (byte offset 256*gl + 32*e)
                 if (gl == 0 && e == 0) load_a4<0>(anext, av[0][0]);
@@ -219,13 +224,27 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
             }
         }
     }
-    {   // drain: the last A loads and DMA pieces are in flight and never used; keep their registers tied up
-        float sink = 0.0f;
+    {
+        // The last chunk: nothing left to fetch (the loop above used to re-load and re-stage the last chunk redundantly), so
+        // everything in flight is drained once and the octets run as bare MFMAs -- and only the octets that hold at least one
+        // real contraction index: with H = 500 the 64th octet (k = 504..511) is zero padding in both operands, 1.6 % of the
+        // MFMAs.  Its weights were published by the barrier of chunk nchunk-2 (or the prologue's): no barrier here.
 #pragma unroll
         for (int gl = 0; gl < G; ++gl)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { wait_vm4<0>(av[gl][e]); sink += av[gl][e][0]; }
-        if (a.tiles < 0) a.out[0] = sink;  // never true
+            for (int e = 0; e < 4; ++e) wait_vm4<0>(av[gl][e]);
+        const int o0 = (nchunk - 1) * G;
+        const int gtail = (a.H + 7) / 8 - o0;  // 1 .. 4 octets with real data (Hp - H < 32)
+#pragma unroll
+        for (int gl = 0; gl < G; ++gl) {
+            if (gl < gtail) {
+                if (gl + 1 < G) { if (gl & 1) read_b(o0 + gl + 1, b0); else read_b(o0 + gl + 1, b1); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (gl & 1) kstep(av[gl][e], b1, e); else kstep(av[gl][e], b0, e);
+                }
+            }
+        }
     }
     if (!live) return;
 
