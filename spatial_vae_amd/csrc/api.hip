@@ -1010,6 +1010,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             w.slab = pl.slab;
             w.bslab = pl.bslab;
             w.noct = g.noct;
+            w.vo = (g.N + 7) / 8; w.po = g.Npad / 8;
             w.Hp = g.Hp;
             w.nblk1 = pl.wg_nblk1;
             w.do_p = pl.do_p; w.out_w = p->out_w; w.wpart = pl.wpart; w.bpart = pl.bpart;

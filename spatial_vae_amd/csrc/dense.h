@@ -595,6 +595,7 @@ struct WgradArgs {
     float* slab;         // [S][Hp][Hp]
     float* bslab;        // [S][2][Hp] partial bias gradients (two half-waves)
     long noct;
+    int vo, po;          // row octets per image that hold at least one real row (ceil(N / 8)), and per padded image (Npad / 8)
     int Hp;
     int nblk1;           // blocks per side = ceil(ntile / 8)
     int S;               // > 0: 1-D XCD-aware grid of nblk1^2 * S workgroups; 0: 2-D grid (blocks, splits)
@@ -635,9 +636,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
     }
     const int bi = blk / a.nblk1, bj = blk % a.nblk1;
     const int ibase = bi * 8 + (wave >> 1) * 4, jbase = bj * 8 + (wave & 1) * 4;
-    const long per = (a.noct + S - 1) / S;
+    // The contraction runs over the row octets that hold real rows: an image padded from N to Npad rows ends in (Npad - N) / 8
+    // all-padding octets (28 x 28: 2 of 100) whose gradient rows are exactly zero, so they are not fetched or multiplied at all.
+    // o counts those octets compactly; octet_of(o) = (o / vo) po + o % vo is kept incrementally by the DMA issue below.
+    const long nco = (a.noct / a.po) * a.vo;
+    const long per = (nco + S - 1) / S;
     const long o0 = split * per;
-    const long o1 = (o0 + per < a.noct) ? o0 + per : a.noct;
+    const long o1 = (o0 + per < nco) ? o0 + per : nco;
 
     const float* pa[4];
     const float* pb[4];
@@ -685,10 +690,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
         vob[t] = (unsigned)((pb[t] - a.aprev) * 4);
     }
     const unsigned vod = (unsigned)(((lane >> 1) < 1 ? (lane & 1) : 0) * 16);  // CL == 1: lanes 0, 1 fetch do_p[8 oc + 4 hh .. +3]
-    auto dma = [&](long o) {
-        const long oc = (o < o1) ? o : o1 - 1;
+    long dma_j = o0, dma_oct = 0;   // next compact octet to fetch and its position in the row space (all wave-uniform)
+    int dma_r = 0;
+    if (o0 < o1) {
+        const long img = o0 / a.vo;
+        dma_r = (int)(o0 - img * a.vo);
+        dma_oct = img * a.po + dma_r;
+    }
+    auto dma = [&](long o) {   // called with o = o0, o0 + 1, ...: beyond the range the last octet is re-loaded (never multiplied)
+        const long oc = dma_oct;
         const long off = oc * ostride;
         const unsigned slot = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((o - o0) & 3) * (kSlotFloats * 4u));
+        ++dma_j;
+        if (dma_j < o1) {
+            ++dma_r; ++dma_oct;
+            if (dma_r == a.vo) { dma_r = 0; dma_oct += a.po - a.vo; }
+        }
         const float* ba = a.dh + off;
         const float* bb = a.aprev + off;
 #pragma unroll
@@ -781,6 +798,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) pw[0][t] += wgt * ((d.x * xa[t].x + d.y * xa[t].y) + (d.z * xa[t].z + d.w * xa[t].w));
         }
+        // (r03: the same transform in packed form -- v_pk_mul_f32 / v_pk_fma_f32, 16 instead of 32 instructions per octet -- was
+        // measured SLOWER here, 0.854 -> 0.867 ms: at one wave per SIMD a packed fp32 instruction costs the matrix pipe more than
+        // the two scalar ones it replaces.  In dense4_kernel, two waves per SIMD, the packed form is the faster one.)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {  // act'(a) d: t = d a, then tanh d - t a = d (1 - a^2), sigmoid t - t a = d a (1 - a)
             const float4 v = xa[t];
