@@ -637,17 +637,24 @@ void launch_split_wgrad(const Geo& g, const Plan& pl, const float* dh, const flo
 // whole 128-row groups, the width whole 64-column blocks, there is no residual and no generic (LASTD == 1) output-layer form,
 // and the launch is large enough for its coarser work quantum (128 rows x 64 columns x K per wave; measured, dense4.h):
 // at least four rounds of the 512 resident workgroups.  SVAE_DENSE4=0 never, =1 whenever legal.
-bool use_dense4(const Geo& g, int resid, int lastd) {
-    const char* e = getenv("SVAE_DENSE4");  // read per call, like SVAE_FUSE_OUT: a test can compare both kernels in one process
-    const int mode = e ? (e[0] == '0' ? 0 : 1) : 2;
-    if (mode == 0 || g.tiles % 4 != 0 || g.ntile % 2 != 0 || resid || lastd == 1) return false;
-    const long wgs = ((g.tiles / 4 + 3) / 4) * (g.ntile / 2);
-    return mode == 1 || wgs >= 2048;
+// Returns the column tiles per workgroup (2 or 1) dense4_kernel should run with, or 0 for dense_kernel.  NT = 2 (64-column
+// blocks, two waves per SIMD) is the fast form but its work quantum is 128 rows x 64 columns x K per wave: below four rounds
+// of the 512 resident workgroups (BASELINE cfg 1: 51 200 rows) the half-size quantum of NT = 1 (three waves per SIMD) balances
+// the chip better (measured: tools/dense4_proto.hip, 0.247 vs 0.234 ms against dense_kernel's 0.240).  SVAE_DENSE4=0 never,
+// =1 / =2: that NT whenever legal.
+int use_dense4(const Geo& g, int resid, int lastd) {
+    const char* e = getenv("SVAE_DENSE4");  // read per call, like SVAE_FUSE_OUT: a test can compare the kernels in one process
+    const int mode = e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 3;
+    if (mode == 0 || g.tiles % 4 != 0 || resid || lastd == 1) return 0;
+    const bool nt2_ok = g.ntile % 2 == 0;
+    if (mode == 2) return nt2_ok ? 2 : 1;
+    if (mode == 1) return 1;
+    const long wgs2 = ((g.tiles / 4 + 3) / 4) * (g.ntile / 2);
+    return (nt2_ok && wgs2 >= 2048) ? 2 : 1;
 }
 
-template <bool DGRAD, bool FIRST, int LASTD, int CF>
+template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
 void launch_dense4_v(const DenseArgs& a, long groups, hipStream_t st) {
-    constexpr int NT = 2;
     const long sets = (groups + 3) / 4;
     const dim3 grid((unsigned)(((sets + 7) / 8) * 8 * ((a.Hp / 32) / NT)));
     // LDS: the two weight buffers, and for FIRST 3 x 128 floats per wave of per-row operands behind them
@@ -662,29 +669,33 @@ int launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = 
     took(DGRAD ? P_DENSE_FP32_DGRAD : P_DENSE_FP32_FWD);
     if (lastd) took(lastd == 1 ? P_OUT_BWD_FUSED_GENERIC : P_OUT_BWD_RANK1);
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
-    if (use_dense4(g, a.resid, lastd)) {
+    if (const int nt4 = use_dense4(g, a.resid, lastd)) {
         took(P_DENSE4);
         const long groups = g.tiles / 4;
-        if constexpr (!DGRAD) {
-            switch (cf) {
-                case 0: launch_dense4_v<false, false, 0, 0>(a, groups, st); break;
-                case 1: launch_dense4_v<false, false, 0, 1>(a, groups, st); break;
-                case 2: launch_dense4_v<false, false, 0, 2>(a, groups, st); break;
-                case 3: launch_dense4_v<false, false, 0, 3>(a, groups, st); break;
-                default: launch_dense4_v<false, false, 0, 4>(a, groups, st); break;
-            }
-        } else {
-            if (first) {
-                if (lastd == 2) launch_dense4_v<true, true, 2, 0>(a, groups, st);
-                else if (lastd == 3) launch_dense4_v<true, true, 3, 0>(a, groups, st);
-                else launch_dense4_v<true, true, 0, 0>(a, groups, st);
+        auto go = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
+            if constexpr (!DGRAD) {
+                switch (cf) {
+                    case 0: launch_dense4_v<NT, false, false, 0, 0>(a, groups, st); break;
+                    case 1: launch_dense4_v<NT, false, false, 0, 1>(a, groups, st); break;
+                    case 2: launch_dense4_v<NT, false, false, 0, 2>(a, groups, st); break;
+                    case 3: launch_dense4_v<NT, false, false, 0, 3>(a, groups, st); break;
+                    default: launch_dense4_v<NT, false, false, 0, 4>(a, groups, st); break;
+                }
             } else {
-                if (lastd == 2) launch_dense4_v<true, false, 2, 0>(a, groups, st);
-                else if (lastd == 3) launch_dense4_v<true, false, 3, 0>(a, groups, st);
-                else launch_dense4_v<true, false, 0, 0>(a, groups, st);
+                if (first) {
+                    if (lastd == 2) launch_dense4_v<NT, true, true, 2, 0>(a, groups, st);
+                    else if (lastd == 3) launch_dense4_v<NT, true, true, 3, 0>(a, groups, st);
+                    else launch_dense4_v<NT, true, true, 0, 0>(a, groups, st);
+                } else {
+                    if (lastd == 2) launch_dense4_v<NT, true, false, 2, 0>(a, groups, st);
+                    else if (lastd == 3) launch_dense4_v<NT, true, false, 3, 0>(a, groups, st);
+                    else launch_dense4_v<NT, true, false, 0, 0>(a, groups, st);
+                }
             }
-        }
-        return 2;
+        };
+        if (nt4 == 2) go(std::integral_constant<int, 2>()); else go(std::integral_constant<int, 1>());
+        return nt4;
     }
     const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
@@ -832,7 +843,9 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
     const bool fuse_env = !(fuse_e && fuse_e[0] == '0');
     const bool split_fwd = split_mode() && (g.act == SVAE_ACT_TANH || g.act == SVAE_ACT_SIGMOID) && g.ntile % 2 == 0;
     const bool fuse_logits = fuse_env && g.L >= 2 &&
-                             (split_fwd ? g.C <= 2 : g.C <= 2 * (use_dense4(g, g.flags & SVAE_FLAG_RESID, 0) ? 2 : dense_nt_first(g.ntile)));
+                             (split_fwd ? g.C <= 2
+                                        : g.C <= 2 * (use_dense4(g, g.flags & SVAE_FLAG_RESID, 0) ? use_dense4(g, g.flags & SVAE_FLAG_RESID, 0)
+                                                                                                   : dense_nt_first(g.ntile)));
 
     launch_prepare(g, pl, p, pa, z, st);
     // fp16x3: bounded operands only, contraction length a multiple of 64

@@ -38,18 +38,19 @@ __device__ __forceinline__ void wait_vm4(f32x4v& v) {
 }
 // act'(a) of the rank-1 output-layer forms for four row operands in two packed instructions (one fma per element costs ~5 %
 // of the launch here, the packed form ~4 %: tools/dense4_proto.hip): tanh 1 - a^2, sigmoid a - a^2
+// act'(a) of the rank-1 output-layer forms for the four row operands of a k-step: tanh 1 - a^2, sigmoid a - a^2.  Plain fma's
+// that the compiler sees (it may pack them itself): r03 tried the packed form from inline asm (v_pk_fma_f32 x 2).  It is ~0.7 %
+// faster in isolation (tools/dense4_proto.hip) but an MFMA may read a VGPR written by a packed-fp32 instruction only two wait
+// states later and hipcc's hazard recognizer does not look inside inline asm: the NT = 1 instantiation came out with ONE wait
+// state and read stale operands (gradients off by 3-30 %), and both repairs -- an s_nop behind the pair, or this slot's
+// row-operand load moved between the pair and the MFMAs -- cost 2.5 % of the launch (0.840 -> 0.862 ms): an idle issue slot in
+// front of an MFMA batch is paid in full.
 template <int LASTD>
 __device__ __forceinline__ f32x4v rank1_actgrad(f32x4v x) {
-    f32x2v lo = {x[0], x[1]}, hi = {x[2], x[3]};
-    if (LASTD == 2) {
-        const f32x2v one = {1.0f, 1.0f};
-        asm volatile("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(lo) : "v"(lo), "v"(one));
-        asm volatile("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(hi) : "v"(hi), "v"(one));
-    } else {
-        asm volatile("v_pk_fma_f32 %0, %1, %1, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(lo) : "v"(lo));
-        asm volatile("v_pk_fma_f32 %0, %1, %1, %1 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(hi) : "v"(hi));
-    }
-    return f32x4v{lo[0], lo[1], hi[0], hi[1]};
+    f32x4v r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(-x[i], x[i], LASTD == 2 ? 1.0f : x[i]);
+    return r;
 }
 
 // Same arguments as dense_kernel (DenseArgs; a.resid must be 0); `groups` = Mp / 128 (the caller guarantees Mp % 128 == 0).
@@ -57,8 +58,14 @@ __device__ __forceinline__ f32x4v rank1_actgrad(f32x4v x) {
 //   FIRST  (DGRAD) data gradient into the coordinate layer: reduce instead of store (dense_kernel's FIRST epilogue)
 //   LASTD  0, or 2 (tanh) / 3 (sigmoid): the rank-1 output-layer form (DGRAD): `in` is a_{L-1}, rows scaled by do[m] in the epilogue
 //   CF     forward of the last hidden layer: the epilogue also contracts with W_o (CF = a.C channels) into a.lpart
+// waves per SIMD the register allocation is sized for: 4 NT accumulator tiles of 16 registers + 64 row-operand registers
+template <int NT>
+struct Dense4Occ {
+    static constexpr int value = NT == 1 ? 3 : 2;
+};
+
 template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
-__global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups) {
+__global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(DenseArgs a, long groups) {
     static_assert(NT == 1 || NT == 2, "4 NT accumulator tiles: two waves per SIMD up to NT = 2");
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(LASTD == 0 || ((LASTD == 2 || LASTD == 3) && DGRAD), "LASTD: the rank-1 data-gradient forms only");
@@ -166,8 +173,7 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
     read_b(0, b0);
     const int spare = nchunk & 1;  // buffer that held chunk nchunk-2: the sink of redundant re-stages
     // one k-step: the four row tiles x NT column tiles that share this A vector and these B values
-    auto kstep = [&](const f32x4v& a4, const float4 (&bf)[NT], int e) {
-        const f32x4v x = LASTD != 0 ? rank1_actgrad<LASTD>(a4) : a4;
+    auto kstep = [&](const f32x4v& x, const float4 (&bf)[NT], int e) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float bv = e == 0 ? bf[t].x : e == 1 ? bf[t].y : e == 2 ? bf[t].z : bf[t].w;
@@ -176,6 +182,25 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
             acc[2][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[2], bv, acc[2][t], 0, 0, 0);
             acc[3][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[3], bv, acc[3][t], 0, 0, 0);
         }
+    };
+    // re-issue the load of register quad (gl, e) for the next chunk (byte offset 256 gl + 32 e)
+    auto reload = [&](int gl, int e, const float* anext) {
+        if (gl == 0 && e == 0) load_a4<0>(anext, av[0][0]);
+        if (gl == 0 && e == 1) load_a4<32>(anext, av[0][1]);
+        if (gl == 0 && e == 2) load_a4<64>(anext, av[0][2]);
+        if (gl == 0 && e == 3) load_a4<96>(anext, av[0][3]);
+        if (gl == 1 && e == 0) load_a4<256>(anext, av[1][0]);
+        if (gl == 1 && e == 1) load_a4<288>(anext, av[1][1]);
+        if (gl == 1 && e == 2) load_a4<320>(anext, av[1][2]);
+        if (gl == 1 && e == 3) load_a4<352>(anext, av[1][3]);
+        if (gl == 2 && e == 0) load_a4<512>(anext, av[2][0]);
+        if (gl == 2 && e == 1) load_a4<544>(anext, av[2][1]);
+        if (gl == 2 && e == 2) load_a4<576>(anext, av[2][2]);
+        if (gl == 2 && e == 3) load_a4<608>(anext, av[2][3]);
+        if (gl == 3 && e == 0) load_a4<768>(anext, av[3][0]);
+        if (gl == 3 && e == 1) load_a4<800>(anext, av[3][1]);
+        if (gl == 3 && e == 2) load_a4<832>(anext, av[3][2]);
+        if (gl == 3 && e == 3) load_a4<864>(anext, av[3][3]);
     };
     // all chunks but the last: MFMAs of chunk c, A loads of chunk c+1, DMA of chunk c+2
     for (int c = 0; c + 1 < nchunk; ++c) {
@@ -196,25 +221,13 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 wait_vm4<15 + P>(av[gl][e]);
-                if (gl & 1) kstep(av[gl][e], b1, e); else kstep(av[gl][e], b0, e);
+                const f32x4v x = LASTD != 0 ? rank1_actgrad<LASTD>(av[gl][e]) : av[gl][e];
+                // all four transforms first, then the MFMAs: the first MFMA then reads a value written three instructions
+                // earlier (left alone, hipcc alternates fma / s_nop 1 / MFMA at NT = 1: two idle wait states per MFMA)
+                if (LASTD != 0) __builtin_amdgcn_sched_barrier(0);
+                if (gl & 1) kstep(x, b1, e); else kstep(x, b0, e);
                 __builtin_amdgcn_sched_barrier(0);
-                // re-issue this register quad's load for the next chunk (byte offset 256*gl + 32*e)
-                if (gl == 0 && e == 0) load_a4<0>(anext, av[0][0]);
-                if (gl == 0 && e == 1) load_a4<32>(anext, av[0][1]);
-                if (gl == 0 && e == 2) load_a4<64>(anext, av[0][2]);
-                if (gl == 0 && e == 3) load_a4<96>(anext, av[0][3]);
-                if (gl == 1 && e == 0) load_a4<256>(anext, av[1][0]);
-                if (gl == 1 && e == 1) load_a4<288>(anext, av[1][1]);
-                if (gl == 1 && e == 2) load_a4<320>(anext, av[1][2]);
-                if (gl == 1 && e == 3) load_a4<352>(anext, av[1][3]);
-                if (gl == 2 && e == 0) load_a4<512>(anext, av[2][0]);
-                if (gl == 2 && e == 1) load_a4<544>(anext, av[2][1]);
-                if (gl == 2 && e == 2) load_a4<576>(anext, av[2][2]);
-                if (gl == 2 && e == 3) load_a4<608>(anext, av[2][3]);
-                if (gl == 3 && e == 0) load_a4<768>(anext, av[3][0]);
-                if (gl == 3 && e == 1) load_a4<800>(anext, av[3][1]);
-                if (gl == 3 && e == 2) load_a4<832>(anext, av[3][2]);
-                if (gl == 3 && e == 3) load_a4<864>(anext, av[3][3]);
+                reload(gl, e, anext);
                 if (gl == G - 1) {  // this wave's DMA pieces of chunk c+2, PE per k-step
 #pragma unroll
                     for (int j = 0; j < PE; ++j)
@@ -241,7 +254,10 @@ __global__ __launch_bounds__(256, 2) void dense4_kernel(DenseArgs a, long groups
                 if (gl + 1 < G) { if (gl & 1) read_b(o0 + gl + 1, b0); else read_b(o0 + gl + 1, b1); }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (gl & 1) kstep(av[gl][e], b1, e); else kstep(av[gl][e], b0, e);
+                    const f32x4v x = LASTD != 0 ? rank1_actgrad<LASTD>(av[gl][e]) : av[gl][e];
+                    if (LASTD != 0) __builtin_amdgcn_sched_barrier(0);
+                    if (gl & 1) kstep(x, b1, e); else kstep(x, b0, e);
+                    if (LASTD != 0) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

@@ -29,6 +29,7 @@ CASES = [
     ("relu_c1_coords", 8, 6, 2, 64, 2, 1, nn.ReLU, False),        # explicit coordinates (forward(x, z)), rectifier
     ("leaky_c2_coords", 12, 8, 0, 64, 2, 2, nn.LeakyReLU, False), # z_dim 0, 144 pixels (Npad 160: 5 tiles per image)
     ("tanh_h500", 28, 8, 2, 500, 2, 1, nn.Tanh, True),            # BASELINE width, 25 tiles per image
+    ("tanh_h96_odd_tiles", 8, 6, 2, 96, 3, 2, nn.Tanh, True),     # three column tiles: NT = 2 is not legal, NT = 1 is
 ]
 
 
@@ -69,10 +70,13 @@ def _run(case, mode, monkeypatch):
     return out, counts
 
 
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["nt1", "nt2"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_dense4_matches_dense_kernel(case, monkeypatch):
+def test_dense4_matches_dense_kernel(case, mode, monkeypatch):
+    """SVAE_DENSE4=1: 32-column blocks, three waves per SIMD (the form small launches take); =2: 64-column blocks, two waves
+    per SIMD (the form the BASELINE sizes of configs 2-5 take; an odd number of column tiles falls back to 1)."""
     old, c_old = _run(case, "0", monkeypatch)
-    new, c_new = _run(case, "1", monkeypatch)
+    new, c_new = _run(case, mode, monkeypatch)
     L = case[5]
     assert c_old.get("dense4", 0) == 0
     assert c_new["dense4"] == 2 * (L - 1), c_new                     # every hidden-layer GEMM, forward and data gradient
@@ -88,6 +92,7 @@ def test_dense4_forward_activations_are_bit_identical(monkeypatch):
     monkeypatch.setenv("SVAE_FUSE_LOGITS", "0")
     case = ("bits", 8, 6, 2, 64, 2, 3, nn.Tanh, True)
     old, _ = _run(case, "0", monkeypatch)
-    new, c_new = _run(case, "1", monkeypatch)
-    assert c_new["dense4"] == 2
-    assert np.array_equal(old["y"], new["y"]) and np.array_equal(old["logits"], new["logits"])
+    for mode in ("1", "2"):
+        new, c_new = _run(case, mode, monkeypatch)
+        assert c_new["dense4"] == 2
+        assert np.array_equal(old["y"], new["y"]) and np.array_equal(old["logits"], new["logits"]), mode

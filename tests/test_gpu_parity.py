@@ -208,3 +208,12 @@ def test_display_paths_match_reference(name):
         assert rel_err(rnd.cpu().numpy(), gold["random.y_hat"]) < TOL
     assert got.shape == gold["display.y_hat"].shape
     assert rel_err(got.cpu().numpy(), gold["display.y_hat"]) < TOL
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in C.CASES if not c["resid"]])
+def test_goldens_with_dense_kernel_forced(name, monkeypatch):
+    """The default dispatch takes dense4_kernel wherever the padded row space is whole 128-row groups (most golden cases: 4
+    images of 64 padded rows); SVAE_DENSE4=0 keeps every hidden-layer GEMM on dense_kernel, which small or ragged launches and
+    residual nets still take, so both kernels meet the reference's outputs."""
+    monkeypatch.setenv("SVAE_DENSE4", "0")
+    test_eval_minibatch_matches_reference(name)
