@@ -209,8 +209,10 @@ def traffic_for(kind, cfg_id, split):
     gfx950 correction applied).  Returns (bytes | None, profile file | None): the value is NOT measured in this run, so
     the line names the profile it came from."""
     import glob
-    suffix = ("_cfg%d" % cfg_id if cfg_id != 2 else "") + ("_fp16x3" if split else "")
+    suffix = "_cfg%d" % cfg_id + ("_fp16x3" if split else "")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic%s.json" % suffix)))
+    if not files and cfg_id == 2:       # r01 / r02 named the headline config's file without a suffix
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic%s.json" % ("_fp16x3" if split else ""))))
     if not files:
         return None, None
     try:
@@ -220,12 +222,16 @@ def traffic_for(kind, cfg_id, split):
     if split:
         want = {"dense_fwd": "svae::dense_split_kernel<4, 0", "dense_dgrad": "svae::dense_split_kernel<4, 2",
                 "wgrad": "svae::split_wgrad_kernel"}[kind]
-    else:
-        want = {"dense_fwd": "svae::dense_kernel<4, false", "dense_dgrad": "svae::dense_kernel<4, true",
-                "wgrad": "svae::wgrad_kernel"}[kind]
-    for name, d in prof.items():
-        if name.startswith(want):
-            return d.get("hbm_bytes_corrected"), os.path.relpath(files[-1], ROOT)
+    else:   # the hidden-layer GEMMs run on dense4_kernel at the BASELINE sizes (dense_kernel for small launches)
+        want = {"dense_fwd": ("svae::dense4_kernel<2, false", "svae::dense4_kernel<1, false", "svae::dense_kernel<4, false"),
+                "dense_dgrad": ("svae::dense4_kernel<2, true", "svae::dense4_kernel<1, true", "svae::dense_kernel<4, true"),
+                "wgrad": ("svae::wgrad_kernel",)}[kind]
+    if isinstance(want, str):
+        want = (want,)
+    for w in want:
+        hits = [d for name, d in prof.items() if name.startswith(w)]
+        if hits:    # several instantiations of one role (L = 3: plain and fused forms): the launch with the most bytes
+            return max(h.get("hbm_bytes_corrected") or 0 for h in hits), os.path.relpath(files[-1], ROOT)
     return None, None
 
 

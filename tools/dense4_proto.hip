@@ -19,7 +19,8 @@ int main(int argc, char** argv) {
     const int H = argc > 1 ? atoi(argv[1]) : 500;
     const long B = argc > 2 ? atol(argv[2]) : 256;
     const int Hp = (H + 31) / 32 * 32, ntile = Hp / 32;
-    const long Mp = B * 800, tiles = Mp / 32, groups = Mp / 128;
+    const long rows_per_image = argc > 3 ? atol(argv[3]) : 800;   // padded rows per image (28 x 28: 800)
+    const long Mp = B * rows_per_image, tiles = Mp / 32, groups = Mp / 128;
     printf("H %d Hp %d Mp %ld tiles %ld groups %ld\n", H, Hp, Mp, tiles, groups);
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
@@ -104,7 +105,7 @@ int main(int argc, char** argv) {
             float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 4;
             best = ms < best ? ms : best; sum += ms;
         }
-        printf("%-22s best %.4f ms  mean %.4f ms  (%.1f TFLOP/s algorithmic at H=%d)\n", what, best, sum / 5, 2.0 * (B * 784) * H * H / best / 1e9, H);
+        printf("%-22s best %.4f ms  mean %.4f ms  (%.1f TFLOP/s algorithmic at H=%d)\n", what, best, sum / 5, 2.0 * (double)Mp * (784.0 / 800.0) * H * H / best / 1e9, H);
     };
     for (int rep = 0; rep < 2; ++rep) {   // interleaved rounds in one process
         timeit(run0, "dense_kernel<4>");

@@ -27,11 +27,13 @@ def per_kernel(d):
 
 def main():
     fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/kbench.py at BASELINE "
-                   "cfg 2; KB per dispatch. gfx950: FETCH_SIZE reads exactly half the bytes of wide (16 B/lane) "
+    what = sys.argv[4] if len(sys.argv) > 4 else "BASELINE cfg 2"
+    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/kbench.py at " + what +
+                   "; KB per dispatch. gfx950: FETCH_SIZE reads exactly half the bytes of wide (16 B/lane) "
                    "coalesced streaming reads (MI355X_MICROARCH.md, HBM): 'hbm_bytes_corrected' = (2*FETCH_SIZE + "
-                   "WRITE_SIZE)*1024; the dense kernels' row operand is read with 4 B/lane loads, for which the "
-                   "counter is uncalibrated, so their corrected figure is an upper bound.",
+                   "WRITE_SIZE)*1024; dense4_kernel and wgrad_kernel read with 16 B/lane (the correction applies); "
+                   "dense_kernel's row operand is read with 4 B/lane loads, for which the counter is uncalibrated, so its "
+                   "corrected figure is an upper bound.",
            "kernels": {}}
     for k in fetch:
         f, w = fetch[k], write.get(k, 0.0)
