@@ -322,10 +322,10 @@ static_assert(K_COUNT <= SVAE_PROF_KINDS, "svae_profile_read arrays too small");
 // geometry (fp16x3 falls back to the fp32 kernels for unbounded activations and odd tile counts), and a test must be able
 // to tell a run of the split kernels from a silent fallback
 enum Path { P_DENSE_FP32_FWD = 0, P_DENSE_FP32_DGRAD, P_WGRAD_FP32, P_DENSE_SPLIT_FWD, P_DENSE_SPLIT_DGRAD, P_WGRAD_SPLIT,
-            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_DENSE4, P_COUNT };
+            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_DENSE4, P_DENSE4_TAIL, P_COUNT };
 const char* const kPathNames[SVAE_PATH_KINDS] = {"dense_fp32_fwd", "dense_fp32_dgrad", "wgrad_fp32", "dense_split_fwd",
                                                   "dense_split_dgrad", "wgrad_split", "out_bwd_stream", "out_bwd_split",
-                                                  "out_bwd_rank1", "out_bwd_fused_generic", "dense4", "", "", "", "", ""};
+                                                  "out_bwd_rank1", "out_bwd_fused_generic", "dense4", "dense4_tail", "", "", "", ""};
 static_assert(P_COUNT <= SVAE_PATH_KINDS, "svae_path_counts array too small");
 std::atomic<long long> g_path[SVAE_PATH_KINDS];
 inline void took(int path) { g_path[path].fetch_add(1, std::memory_order_relaxed); }
@@ -654,48 +654,93 @@ int use_dense4(const Geo& g, int resid, int lastd) {
 }
 
 template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
-void launch_dense4_v(const DenseArgs& a, long groups, hipStream_t st) {
-    const long sets = (groups + 3) / 4;
-    const dim3 grid((unsigned)(((sets + 7) / 8) * 8 * ((a.Hp / 32) / NT)));
+void launch_dense4_v(const DenseArgs& a, long groups, long set0, long nsets, hipStream_t st) {
+    const dim3 grid((unsigned)(((nsets + 7) / 8) * 8 * ((a.Hp / 32) / NT)));
     // LDS: the two weight buffers, and for FIRST 3 x 128 floats per wave of per-row operands behind them
     constexpr int lds = DenseCfg<NT>::LDS_BYTES + (FIRST ? 4 * 3 * 128 * 4 : 0);
-    hipLaunchKernelGGL((dense4_kernel<NT, DGRAD, FIRST, LASTD, CF>), grid, dim3(256), lds, st, a, groups);
+    // the grid is padded to whole XCD octets of sets: row groups beyond this launch's sets are dead in it (they belong to the
+    // other launch of a split layer, or do not exist)
+    const long gend = (set0 + nsets) * 4 < groups ? (set0 + nsets) * 4 : groups;
+    hipLaunchKernelGGL((dense4_kernel<NT, DGRAD, FIRST, LASTD, CF>), grid, dim3(256), lds, st, a, gend, set0);
 }
 
-// returns the number of column tiles per workgroup the launch used (its partial results -- a.lpart, a.dfpart -- come per
-// column block of 32 x that many columns)
+// How a hidden-layer GEMM was launched: column tiles per workgroup (its partial results -- a.lpart, a.dfpart -- come per column
+// block of 32 x that many columns), and, when the layer was split in two launches, the first padded row of the half-width
+// tail launch and its column tiles per workgroup (m_split = Mp: one launch).
+struct DenseBlocks {
+    int nt;
+    long m_split;
+    int nt_tail;
+};
+
+// The last partial round of a dense4_kernel<2> launch runs one workgroup per CU, and a wave's unit (128 rows x 64 columns x K)
+// is serial on its SIMD: measured at BASELINE cfg 2, 3200 workgroups take 8.0 % longer than 3072 for 4.2 % more rows
+// (profiles/r03_dense4_tail.txt).  When the launch is a few rounds long and its last round is less than half full, the sets
+// of that round run as a second launch at half the block width (dense4_kernel<1>: twice the workgroups, half the unit).
+// Returns the number of sets the wide launch keeps (all of them: no split).  tail_ok: the partial buffers have room for the
+// tail's 32-column blocks (C <= 2 for the logits partials).
+long dense4_main_sets(const Geo& g, long sets, bool tail_ok) {
+    const char* e = getenv("SVAE_DENSE4_TAIL");   // "0": never split; "=<k>": the wide launch keeps k sets (tests)
+    if ((e && e[0] == '0') || !tail_ok) return sets;
+    if (e && e[0] == '=') {
+        const long k = atol(e + 1);
+        return (k > 0 && k < sets) ? k : sets;
+    }
+    static const long slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return (long)cus * 2;   // two resident workgroups of dense4_kernel<2> per CU
+    }();
+    const long nblk = g.ntile / 2;
+    const long W = sets * nblk;
+    if (slots % nblk != 0) return sets;
+    const long full = (W / slots) * slots, rest = W - full;
+    if (full < 2 * slots || rest == 0 || W >= 16 * slots || 20 * rest > 9 * slots) return sets;   // 2..16 rounds, last <= 0.45 full
+    return full / nblk;
+}
+
 template <bool DGRAD>
-int launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
+DenseBlocks launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
     took(DGRAD ? P_DENSE_FP32_DGRAD : P_DENSE_FP32_FWD);
     if (lastd) took(lastd == 1 ? P_OUT_BWD_FUSED_GENERIC : P_OUT_BWD_RANK1);
     Scope prof(DGRAD ? K_DENSE_DGRAD : K_DENSE_FWD, st);
     if (const int nt4 = use_dense4(g, a.resid, lastd)) {
         took(P_DENSE4);
         const long groups = g.tiles / 4;
-        auto go = [&](auto nt_tag) {
+        const long sets = (groups + 3) / 4;
+        auto go = [&](auto nt_tag, long set0, long nsets) {
             constexpr int NT = decltype(nt_tag)::value;
             if constexpr (!DGRAD) {
                 switch (cf) {
-                    case 0: launch_dense4_v<NT, false, false, 0, 0>(a, groups, st); break;
-                    case 1: launch_dense4_v<NT, false, false, 0, 1>(a, groups, st); break;
-                    case 2: launch_dense4_v<NT, false, false, 0, 2>(a, groups, st); break;
-                    case 3: launch_dense4_v<NT, false, false, 0, 3>(a, groups, st); break;
-                    default: launch_dense4_v<NT, false, false, 0, 4>(a, groups, st); break;
+                    case 0: launch_dense4_v<NT, false, false, 0, 0>(a, groups, set0, nsets, st); break;
+                    case 1: launch_dense4_v<NT, false, false, 0, 1>(a, groups, set0, nsets, st); break;
+                    case 2: launch_dense4_v<NT, false, false, 0, 2>(a, groups, set0, nsets, st); break;
+                    case 3: launch_dense4_v<NT, false, false, 0, 3>(a, groups, set0, nsets, st); break;
+                    default: launch_dense4_v<NT, false, false, 0, 4>(a, groups, set0, nsets, st); break;
                 }
             } else {
                 if (first) {
-                    if (lastd == 2) launch_dense4_v<NT, true, true, 2, 0>(a, groups, st);
-                    else if (lastd == 3) launch_dense4_v<NT, true, true, 3, 0>(a, groups, st);
-                    else launch_dense4_v<NT, true, true, 0, 0>(a, groups, st);
+                    if (lastd == 2) launch_dense4_v<NT, true, true, 2, 0>(a, groups, set0, nsets, st);
+                    else if (lastd == 3) launch_dense4_v<NT, true, true, 3, 0>(a, groups, set0, nsets, st);
+                    else launch_dense4_v<NT, true, true, 0, 0>(a, groups, set0, nsets, st);
                 } else {
-                    if (lastd == 2) launch_dense4_v<NT, true, false, 2, 0>(a, groups, st);
-                    else if (lastd == 3) launch_dense4_v<NT, true, false, 3, 0>(a, groups, st);
-                    else launch_dense4_v<NT, true, false, 0, 0>(a, groups, st);
+                    if (lastd == 2) launch_dense4_v<NT, true, false, 2, 0>(a, groups, set0, nsets, st);
+                    else if (lastd == 3) launch_dense4_v<NT, true, false, 3, 0>(a, groups, set0, nsets, st);
+                    else launch_dense4_v<NT, true, false, 0, 0>(a, groups, set0, nsets, st);
                 }
             }
         };
-        if (nt4 == 2) go(std::integral_constant<int, 2>()); else go(std::integral_constant<int, 1>());
-        return nt4;
+        if (nt4 == 1) {
+            go(std::integral_constant<int, 1>(), 0, sets);
+            return DenseBlocks{1, (long)g.Mp, 1};
+        }
+        const long main_sets = dense4_main_sets(g, sets, cf <= 2);
+        go(std::integral_constant<int, 2>(), 0, main_sets);
+        if (main_sets < sets) {
+            took(P_DENSE4_TAIL);
+            go(std::integral_constant<int, 1>(), main_sets, sets - main_sets);
+        }
+        return DenseBlocks{2, main_sets < sets ? main_sets * 512 : (long)g.Mp, 1};
     }
     const int nt = (first || lastd || cf) ? dense_nt_first(g.ntile) : dense_nt_for(g.ntile);
     static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
@@ -709,7 +754,7 @@ int launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = 
         case 2: launch_dense_nt<2, DGRAD>(a, grid, st, first, lastd, cf); break;
         default: launch_dense_nt<1, DGRAD>(a, grid, st, first, lastd, cf); break;
     }
-    return nt;
+    return DenseBlocks{nt, (long)g.Mp, nt};
 }
 
 template <int CL, int R1 = 0>
@@ -862,7 +907,7 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
             default: launch_layer0_fwd<SVAE_ACT_SIGMOID>(g, pl, pa, pl.act[0], st); break;
         }
     }
-    int cf_nt = dense_nt_first(g.ntile);  // column tiles per block of the launch that wrote the partial logits
+    DenseBlocks cfb{dense_nt_first(g.ntile), (long)g.Mp, 1};  // how the launch that wrote the partial logits was blocked
     for (int l = 1; l < g.L; ++l) {
         if (split) {
             launch_split_fwd(g, pl, pl.act[l - 1], p->hidden_w[l - 1], p->hidden_b[l - 1], pl.act[l],
@@ -885,25 +930,27 @@ int decoder_forward_impl(const svae_desc* d, const svae_params* p, const svae_po
         a.Mp = g.Mp; a.N = g.N; a.Timg = g.Timg;
         a.do_p = nullptr; a.out_w = p->out_w; a.C = g.C;
         a.lpart = pl.dfpart;  // free during the forward pass; nblk * C * Mp <= ntile * 2 * Mp floats
-        const int nt_used = launch_dense<false>(g, a, st, false, 0, (fuse_logits && l == g.L - 1) ? g.C : 0);
-        if (l == g.L - 1) cf_nt = nt_used;
+        const DenseBlocks used = launch_dense<false>(g, a, st, false, 0, (fuse_logits && l == g.L - 1) ? g.C : 0);
+        if (l == g.L - 1) cfb = used;
     }
     if (fuse_logits) {
         Scope prof(K_OUT_FWD, st);
-        const int nblk = g.ntile / (split ? split_nt_fwd(g) : cf_nt);
+        const int nblk = g.ntile / (split ? split_nt_fwd(g) : cfb.nt);
+        const long m_split = split ? (long)g.Mp : cfb.m_split;
+        const int nblk_tail = g.ntile / cfb.nt_tail;
         if (bce_target) {
             // one block per (image, chunk of <= 1024 pixels); with several chunks per image (galaxy: 16 384 pixels) their
             // sums go to llpart and are added in chunk order by loglik_reduce_kernel (fixed order, no atomics)
             const int chunks = finish_chunks(g.N);
             hipLaunchKernelGGL(logits_finish_bce_kernel, dim3(g.B, chunks), dim3(g.N > 512 ? 1024 : (g.N > 256 ? 512 : 256)), 0, st,
                                pl.dfpart, p->out_b, bce_target, y, logits, chunks > 1 ? pl.llpart : loglik, dll_dy, row_geo(g), g.C,
-                               nblk, (long)g.Mp);
+                               nblk, (long)g.Mp, m_split, nblk_tail);
             if (chunks > 1)
                 hipLaunchKernelGGL(loglik_reduce_kernel, dim3(blocks_for(g.B)), dim3(256), 0, st, pl.llpart, loglik, g.B, chunks);
         }
         else
             hipLaunchKernelGGL(logits_finish_kernel, dim3(blocks_for((long)g.B * g.N)), dim3(256), 0, st, pl.dfpart, p->out_b, y,
-                               logits, row_geo(g), g.C, nblk, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp);
+                               logits, row_geo(g), g.C, nblk, (g.flags & SVAE_FLAG_SOFTPLUS) ? 1 : 0, (long)g.Mp, m_split, nblk_tail);
         return launch_status("svae_decoder_forward");
     }
     switch (g.C) {
@@ -1009,7 +1056,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
 
     // hidden layers, last to first
     bool fused_first = false;
-    int first_nt = dense_nt_first(g.ntile);  // column tiles per block of the fp32 launch that ran the FIRST epilogue
+    DenseBlocks fb{dense_nt_first(g.ntile), (long)g.Mp, 1};  // how the fp32 launch that ran the FIRST epilogue was blocked
     for (int l = g.L - 1; l >= 1; --l) {
         const bool last = fused_out && l == g.L - 1;
         // fp16x3 runs down the stack: every split data gradient leaves the scale of its result for the layer below
@@ -1071,8 +1118,8 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             launch_split_dgrad(g, pl, pl.dh[cur], p->hidden_w[l - 1], pl.act[l - 1], pl.dh[cur ^ 1], resid != 0, fused_first, pa,
                                split_ob && l == g.L - 1, st);
         else {
-            const int nt_used = launch_dense<true>(g, a, st, fused_first, last ? (r1 ? (g.act == SVAE_ACT_TANH ? 2 : 3) : 1) : 0);
-            if (l == 1) first_nt = nt_used;
+            const DenseBlocks used = launch_dense<true>(g, a, st, fused_first, last ? (r1 ? (g.act == SVAE_ACT_TANH ? 2 : 3) : 1) : 0);
+            if (l == 1) fb = used;
         }
         cur ^= 1;
     }
@@ -1090,9 +1137,9 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
             hipLaunchKernelGGL(first_layer_image_kernel, dim3(g.B, want_coords ? 2 : 1), dim3(256), 0, st, pl.sgtile,
                                split_first ? 2 : 1, g.Timg, g.H, g.Hp, pl.sgimg, p->latent_w, bil ? p->bilinear_w : nullptr,
                                want_dz ? dz : (float*)nullptr, g.Zd, g.in_dim, pl.dfpart,
-                               g.ntile / (split_first ? split_nt(g) : first_nt), g.N, g.Npad, (long)g.Mp,
+                               g.ntile / (split_first ? split_nt(g) : fb.nt), g.N, g.Npad, (long)g.Mp,
                                want_coords ? dc : (float*)nullptr, pose->grid, pl.posebuf, pg ? pg->dtheta : (float*)nullptr,
-                               pg ? pg->ddx : (float*)nullptr);
+                               pg ? pg->ddx : (float*)nullptr, split_first ? (long)g.Mp : fb.m_split, g.ntile / fb.nt_tail);
         } else {
             const float* dh0 = pl.dh[cur];
             hipLaunchKernelGGL(layer0_bwd_params_kernel, dim3(blocks_for(g.Hp * 2), g.B * pl.l0_chunks_per_image), dim3(256), 0,

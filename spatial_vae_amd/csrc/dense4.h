@@ -53,7 +53,9 @@ __device__ __forceinline__ f32x4v rank1_actgrad(f32x4v x) {
     return r;
 }
 
-// Same arguments as dense_kernel (DenseArgs; a.resid must be 0); `groups` = Mp / 128 (the caller guarantees Mp % 128 == 0).
+// Same arguments as dense_kernel (DenseArgs; a.resid must be 0); `groups` = Mp / 128 (the caller guarantees Mp % 128 == 0);
+// the launch covers the sets (4 row groups each) from set0 on: a layer may be split into a wide launch over the sets that fill
+// whole rounds of resident workgroups and a half-width launch over the rest (launch_dense in api.hip).
 //   DGRAD  data gradient: the epilogue multiplies by act'(aux)
 //   FIRST  (DGRAD) data gradient into the coordinate layer: reduce instead of store (dense_kernel's FIRST epilogue)
 //   LASTD  0, or 2 (tanh) / 3 (sigmoid): the rank-1 output-layer form (DGRAD): `in` is a_{L-1}, rows scaled by do[m] in the epilogue
@@ -65,7 +67,7 @@ struct Dense4Occ {
 };
 
 template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
-__global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(DenseArgs a, long groups) {
+__global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(DenseArgs a, long groups, long set0) {
     static_assert(NT == 1 || NT == 2, "4 NT accumulator tiles: two waves per SIMD up to NT = 2");
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(LASTD == 0 || ((LASTD == 2 || LASTD == 3) && DGRAD), "LASTD: the rank-1 data-gradient forms only");
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(Dense
     const int nblk = ntile / NT;
     const long local = blockIdx.x >> 3;
     const int nb = (int)(local % nblk);
-    const long set = (local / nblk) * 8 + (blockIdx.x & 7);
+    const long set = set0 + (local / nblk) * 8 + (blockIdx.x & 7);   // set0: this launch's first set of 4 row groups
     const long rg = set * 4 + wave;
     const bool live = rg < groups;
     const long rgl = live ? rg : groups - 1;  // dead waves recompute the last group and store nothing

@@ -186,12 +186,16 @@ __global__ void out_fwd_kernel(const float* __restrict__ a, const float* __restr
 
 // Output layer when the last dense_kernel already contracted a_{L-1} with W_o (CF epilogue): sum the per-column-block
 // partial logits [nblk][C][Mp], add the bias, apply Sigmoid (+softplus).  One thread per (image, pixel).
+// Rows from m_split on carry nblk_tail partials per channel instead of nblk: the GEMM that wrote them ran its last partial round
+// of workgroups at half the block width (launch_dense).  m_split = Mp when the layer was one launch.
 __global__ void logits_finish_kernel(const float* __restrict__ lpart, const float* __restrict__ out_b, float* __restrict__ y,
-                                     float* __restrict__ logits, RowGeo g, int C, int nblk, int softplus, long Mp) {
+                                     float* __restrict__ logits, RowGeo g, int C, int nblk, int softplus, long Mp, long m_split,
+                                     int nblk_tail) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)g.B * g.N) return;
     const int b = (int)(t / g.N), i = (int)(t - (long)b * g.N);
     const long m = (long)b * g.Npad + i;
+    if (m >= m_split) nblk = nblk_tail;
     for (int c = 0; c < C; ++c) {
         float lg = 0.0f;
         for (int k = 0; k < nblk; ++k) lg += lpart[((long)k * C + c) * Mp + m];
@@ -210,7 +214,8 @@ __global__ void logits_finish_kernel(const float* __restrict__ lpart, const floa
 __global__ void __launch_bounds__(1024) logits_finish_bce_kernel(const float* __restrict__ lpart, const float* __restrict__ out_b,
                                                                 const float* __restrict__ target, float* __restrict__ y,
                                                                 float* __restrict__ logits, float* __restrict__ loglik,
-                                                                float* __restrict__ dll, RowGeo g, int C, int nblk, long Mp) {
+                                                                float* __restrict__ dll, RowGeo g, int C, int nblk, long Mp,
+                                                                long m_split, int nblk_tail) {
     __shared__ float red[16];
     const int b = blockIdx.x;
     float acc = 0.0f;
@@ -221,9 +226,10 @@ __global__ void __launch_bounds__(1024) logits_finish_bce_kernel(const float* __
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const long m = (long)b * g.Npad + i;
         const long t = (long)b * g.N + i;
+        const int nbk = m >= m_split ? nblk_tail : nblk;
         for (int c = 0; c < C; ++c) {
             float lg = 0.0f;
-            for (int k = 0; k < nblk; ++k) lg += lpart[((long)k * C + c) * Mp + m];
+            for (int k = 0; k < nbk; ++k) lg += lpart[((long)k * C + c) * Mp + m];
             lg += out_b[c];
             const float s = 1.0f / (1.0f + expf(-lg));
             const float tg = target[t * C + c];
@@ -488,7 +494,8 @@ __global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __r
                                                                 int in_dim, const float* __restrict__ dfpart, int nblocks, int N,
                                                                 int Npad, long Mp, float* __restrict__ dcoords,
                                                                 const float* __restrict__ grid, const float4* __restrict__ posebuf,
-                                                                float* __restrict__ dtheta, float* __restrict__ ddx) {
+                                                                float* __restrict__ dtheta, float* __restrict__ ddx, long m_split,
+                                                                int nblocks_tail) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     if (blockIdx.y == 0) {
@@ -540,7 +547,8 @@ __global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __r
     for (int i = threadIdx.x; i < N; i += 256) {
         const long mp = (long)b * Npad + i;
         float d0 = 0.0f, d1 = 0.0f;
-        for (int nb = 0; nb < nblocks; ++nb) {
+        const int nbk = mp >= m_split ? nblocks_tail : nblocks;   // rows of a half-width tail launch carry twice the partials
+        for (int nb = 0; nb < nbk; ++nb) {
             const float2 v = *reinterpret_cast<const float2*>(dfpart + ((long)nb * Mp + mp) * 2);
             d0 += v.x; d1 += v.y;
         }

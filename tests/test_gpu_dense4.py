@@ -96,3 +96,34 @@ def test_dense4_forward_activations_are_bit_identical(monkeypatch):
         new, c_new = _run(case, mode, monkeypatch)
         assert c_new["dense4"] == 2
         assert np.array_equal(old["y"], new["y"]) and np.array_equal(old["logits"], new["logits"]), mode
+
+
+TAIL_CASES = [
+    # 20 images of 64 padded rows = 1280 rows = 2.5 sets of 512 rows: the forced split leaves 1 set wide, 1.5 sets to the tail
+    ("tail_tanh_c1_rank1", 8, 20, 2, 64, 2, 1, nn.Tanh, True),
+    ("tail_tanh_c2_stream", 8, 20, 2, 100, 2, 2, nn.Tanh, True),
+    ("tail_tanh_c3_L3", 8, 20, 3, 64, 3, 3, nn.Tanh, True),
+    ("tail_relu_coords", 8, 20, 2, 64, 2, 1, nn.ReLU, False),
+    ("tail_tanh_h500", 28, 8, 2, 500, 2, 1, nn.Tanh, True),           # 6400 rows, the split falls inside an image (800 rows)
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_split_layer_launch_matches_single_launch(case, monkeypatch):
+    """A dense4_kernel<2> launch whose last round of workgroups is less than half full hands the sets of that round to a
+    second launch at half the block width (launch_dense: BASELINE cfg 2 is such a launch).  The rows of the two launches then
+    carry different numbers of per-column-block partials (logits, d(coords)), which the finish kernels must pick per row.
+    SVAE_DENSE4_TAIL==<k> forces the split after k sets of 512 rows at test sizes; results must equal the single launch's."""
+    monkeypatch.setenv("SVAE_DENSE4_TAIL", "0")
+    one, c_one = _run(case, "2", monkeypatch)
+    monkeypatch.setenv("SVAE_DENSE4_TAIL", "=1")
+    two, c_two = _run(case, "2", monkeypatch)
+    B, n = case[2], case[1]
+    rows = B * ((n * n + 31) // 32 * 32)
+    assert rows > 512, "the case must span more than one set for the split to exist"
+    assert c_one.get("dense4_tail", 0) == 0
+    expect = 2 * (case[5] - 1) if case[6] <= 2 else 2 * (case[5] - 1) - 1      # C = 3: the logits partials have no room for a tail
+    assert c_two["dense4_tail"] == expect, c_two
+    for k in one:
+        e = rel_err(two[k], one[k])
+        assert e < (1e-5 if case[4] >= 500 else 2e-6), (case[0], k, e)

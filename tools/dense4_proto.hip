@@ -12,7 +12,7 @@ void launch4(const DenseArgs& a, long groups, hipStream_t st) {
     const int nblk = (a.Hp / 32) / NT;
     const long sets = (groups + 3) / 4;
     const dim3 grid((unsigned)(((sets + 7) / 8) * 8 * nblk));
-    hipLaunchKernelGGL((dense4_kernel<NT, false, false, 0, 0>), grid, dim3(256), lds, st, a, groups);
+    hipLaunchKernelGGL((dense4_kernel<NT, false, false, 0, 0>), grid, dim3(256), lds, st, a, groups, 0L);
 }
 
 int main(int argc, char** argv) {
