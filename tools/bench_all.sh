@@ -1,6 +1,6 @@
 # usage: bash tools/bench_all.sh <tag>  -- one bench.py line per BASELINE config (with cpu_baseline), into gpurun_out/<tag>_bench_cfg<N>.json
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 for c in 2 1 3 5 4; do
   steps=30; [ $c = 4 ] && steps=10
   timeout -k 10 600 python bench.py --config $c --steps $steps --warmup 3 --cpu-seconds 8 > gpurun_out/${TAG}_bench_cfg$c.log 2>&1
