@@ -699,6 +699,17 @@ long dense4_main_sets(const Geo& g, long sets, bool tail_ok) {
     return full / nblk;
 }
 
+// wide workgroups over the sets [0, main_sets), half-width ones over [main_sets, sets): one launch (dense4_dual_kernel)
+template <bool DGRAD, bool FIRST, int LASTD, int CF>
+void launch_dense4_dual(const DenseArgs& a, long groups, long sets, long main_sets, hipStream_t st) {
+    const unsigned ntile = (unsigned)(a.Hp / 32);
+    const unsigned grid_main = (unsigned)(((main_sets + 7) / 8) * 8) * (ntile / 2);
+    const unsigned grid_tail = (unsigned)(((sets - main_sets + 7) / 8) * 8) * ntile;
+    constexpr int lds = DenseCfg<2>::LDS_BYTES + (FIRST ? 4 * 3 * 128 * 4 : 0);
+    hipLaunchKernelGGL((dense4_dual_kernel<DGRAD, FIRST, LASTD, CF>), dim3(grid_main + grid_tail), dim3(256), lds, st, a, groups,
+                       main_sets, grid_main);
+}
+
 template <bool DGRAD>
 DenseBlocks launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool first = false, int lastd = 0, int cf = 0) {
     took(DGRAD ? P_DENSE_FP32_DGRAD : P_DENSE_FP32_FWD);
@@ -734,11 +745,31 @@ DenseBlocks launch_dense(const Geo& g, const DenseArgs& a, hipStream_t st, bool 
             go(std::integral_constant<int, 1>(), 0, sets);
             return DenseBlocks{1, (long)g.Mp, 1};
         }
-        const long main_sets = dense4_main_sets(g, sets, cf <= 2);
-        go(std::integral_constant<int, 2>(), 0, main_sets);
-        if (main_sets < sets) {
-            took(P_DENSE4_TAIL);
-            go(std::integral_constant<int, 1>(), main_sets, sets - main_sets);
+        if (cf > 2) {   // three or four output channels: the logits partials have no room for 32-column blocks
+            if constexpr (!DGRAD) {
+                if (cf == 3) launch_dense4_v<2, false, false, 0, 3>(a, groups, 0, sets, st);
+                else launch_dense4_v<2, false, false, 0, 4>(a, groups, 0, sets, st);
+            }
+            return DenseBlocks{2, (long)g.Mp, 1};
+        }
+        const long main_sets = dense4_main_sets(g, sets, true);
+        if (main_sets < sets) took(P_DENSE4_TAIL);
+        if constexpr (!DGRAD) {
+            switch (cf) {
+                case 0: launch_dense4_dual<false, false, 0, 0>(a, groups, sets, main_sets, st); break;
+                case 1: launch_dense4_dual<false, false, 0, 1>(a, groups, sets, main_sets, st); break;
+                default: launch_dense4_dual<false, false, 0, 2>(a, groups, sets, main_sets, st); break;
+            }
+        } else {
+            if (first) {
+                if (lastd == 2) launch_dense4_dual<true, true, 2, 0>(a, groups, sets, main_sets, st);
+                else if (lastd == 3) launch_dense4_dual<true, true, 3, 0>(a, groups, sets, main_sets, st);
+                else launch_dense4_dual<true, true, 0, 0>(a, groups, sets, main_sets, st);
+            } else {
+                if (lastd == 2) launch_dense4_dual<true, false, 2, 0>(a, groups, sets, main_sets, st);
+                else if (lastd == 3) launch_dense4_dual<true, false, 3, 0>(a, groups, sets, main_sets, st);
+                else launch_dense4_dual<true, false, 0, 0>(a, groups, sets, main_sets, st);
+            }
         }
         return DenseBlocks{2, main_sets < sets ? main_sets * 512 : (long)g.Mp, 1};
     }

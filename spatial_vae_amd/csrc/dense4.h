@@ -66,8 +66,10 @@ struct Dense4Occ {
     static constexpr int value = NT == 1 ? 3 : 2;
 };
 
+// The workgroup's program, shared by dense4_kernel (one block width per launch) and dense4_dual_kernel (both widths in one
+// launch); `bid` is the workgroup's index among those of its width.
 template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
-__global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(DenseArgs a, long groups, long set0) {
+__device__ __forceinline__ void dense4_body(const DenseArgs& a, long groups, long set0, unsigned bid) {
     static_assert(NT == 1 || NT == 2, "4 NT accumulator tiles: two waves per SIMD up to NT = 2");
     static_assert(!FIRST || DGRAD, "FIRST is a data-gradient epilogue");
     static_assert(LASTD == 0 || ((LASTD == 2 || LASTD == 3) && DGRAD), "LASTD: the rank-1 data-gradient forms only");
@@ -84,9 +86,9 @@ __global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(Dense
     const int ntile = Hp / 32;
     // 1-D XCD-aware grid: the column blocks of one set of 4 row groups get consecutive ids on ONE XCD (one L2)
     const int nblk = ntile / NT;
-    const long local = blockIdx.x >> 3;
+    const long local = bid >> 3;
     const int nb = (int)(local % nblk);
-    const long set = set0 + (local / nblk) * 8 + (blockIdx.x & 7);   // set0: this launch's first set of 4 row groups
+    const long set = set0 + (local / nblk) * 8 + (bid & 7);   // set0: the first set of 4 row groups of this width's range
     const long rg = set * 4 + wave;
     const bool live = rg < groups;
     const long rgl = live ? rg : groups - 1;  // dead waves recompute the last group and store nothing
@@ -445,6 +447,27 @@ __global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(Dense
         case SVAE_ACT_LEAKYRELU: epi(std::integral_constant<int, SVAE_ACT_LEAKYRELU>()); break;
         case SVAE_ACT_RELU: epi(std::integral_constant<int, SVAE_ACT_RELU>()); break;
         default: epi(std::integral_constant<int, SVAE_ACT_SIGMOID>()); break;
+    }
+}
+
+template <int NT, bool DGRAD, bool FIRST, int LASTD, int CF>
+__global__ __launch_bounds__(256, Dense4Occ<NT>::value) void dense4_kernel(DenseArgs a, long groups, long set0) {
+    dense4_body<NT, DGRAD, FIRST, LASTD, CF>(a, groups, set0, blockIdx.x);
+}
+
+// Both block widths in ONE launch: workgroups [0, grid_main) run 64-column blocks over the sets [0, sets_main), the rest
+// 32-column blocks over the sets from sets_main on -- the half-width units of a layer's last partial round (launch_dense in
+// api.hip) then need no launch of their own: no kernel boundary, and they backfill the CUs as the wide workgroups drain.
+// grid_main is a multiple of 8, so a workgroup's XCD label (id mod 8) is the same in both numberings.  Registers and LDS are
+// the wide form's (two workgroups per CU for either width); sets_main = all sets and no further workgroups is the plain wide
+// launch.
+template <bool DGRAD, bool FIRST, int LASTD, int CF>
+__global__ __launch_bounds__(256, 2) void dense4_dual_kernel(DenseArgs a, long groups, long sets_main, unsigned grid_main) {
+    if (blockIdx.x < grid_main) {
+        const long gmain = sets_main * 4 < groups ? sets_main * 4 : groups;
+        dense4_body<2, DGRAD, FIRST, LASTD, CF>(a, gmain, 0, blockIdx.x);
+    } else {
+        dense4_body<1, DGRAD, FIRST, LASTD, CF>(a, groups, sets_main, blockIdx.x - grid_main);
     }
 }
 

@@ -12,7 +12,7 @@ import sys
 
 
 def family(name):
-    if "dense_kernel" in name or "dense4_kernel" in name or "dense_split" in name:
+    if "dense_kernel" in name or "dense4_" in name or "dense_split" in name:
         return "decoder GEMM fwd/dgrad"
     if "wgrad_kernel" in name or "split_wgrad" in name:
         return "decoder GEMM wgrad"
