@@ -223,9 +223,11 @@ def traffic_for(kind, cfg_id, split):
         want = {"dense_fwd": "svae::dense_split_kernel<4, 0", "dense_dgrad": "svae::dense_split_kernel<4, 2",
                 "wgrad": "svae::split_wgrad_kernel"}[kind]
     else:   # the hidden-layer GEMMs run on dense4_kernel at the BASELINE sizes (dense_kernel for small launches)
-        want = {"dense_fwd": ("svae::dense4_kernel<2, false", "svae::dense4_kernel<1, false", "svae::dense_kernel<4, false"),
-                "dense_dgrad": ("svae::dense4_kernel<2, true", "svae::dense4_kernel<1, true", "svae::dense_kernel<4, true"),
-                "wgrad": ("svae::wgrad_kernel",)}[kind]
+        want = {"dense_fwd": ("svae::dense4_dual_kernel<false", "svae::dense4_kernel<2, false", "svae::dense4_kernel<1, false",
+                              "svae::dense_kernel<4, false"),
+                "dense_dgrad": ("svae::dense4_dual_kernel<true", "svae::dense4_kernel<2, true", "svae::dense4_kernel<1, true",
+                                "svae::dense_kernel<4, true"),
+                "wgrad": ("svae::wgrad2_kernel", "svae::wgrad_kernel")}[kind]
     if isinstance(want, str):
         want = (want,)
     for w in want:

@@ -14,7 +14,7 @@
 
 #include "common.h"
 #include "dense.h"
-#include "dense4.h"
+#include "wgrad2.h"
 #include "elementwise.h"
 #include "encoder.h"
 #include "split.h"
@@ -322,10 +322,10 @@ static_assert(K_COUNT <= SVAE_PROF_KINDS, "svae_profile_read arrays too small");
 // geometry (fp16x3 falls back to the fp32 kernels for unbounded activations and odd tile counts), and a test must be able
 // to tell a run of the split kernels from a silent fallback
 enum Path { P_DENSE_FP32_FWD = 0, P_DENSE_FP32_DGRAD, P_WGRAD_FP32, P_DENSE_SPLIT_FWD, P_DENSE_SPLIT_DGRAD, P_WGRAD_SPLIT,
-            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_DENSE4, P_DENSE4_TAIL, P_COUNT };
+            P_OUT_BWD_STREAM, P_OUT_BWD_SPLIT, P_OUT_BWD_RANK1, P_OUT_BWD_FUSED_GENERIC, P_DENSE4, P_DENSE4_TAIL, P_WGRAD2, P_COUNT };
 const char* const kPathNames[SVAE_PATH_KINDS] = {"dense_fp32_fwd", "dense_fp32_dgrad", "wgrad_fp32", "dense_split_fwd",
                                                   "dense_split_dgrad", "wgrad_split", "out_bwd_stream", "out_bwd_split",
-                                                  "out_bwd_rank1", "out_bwd_fused_generic", "dense4", "dense4_tail", "", "", "", ""};
+                                                  "out_bwd_rank1", "out_bwd_fused_generic", "dense4", "dense4_tail", "wgrad2", "", "", ""};
 static_assert(P_COUNT <= SVAE_PATH_KINDS, "svae_path_counts array too small");
 std::atomic<long long> g_path[SVAE_PATH_KINDS];
 inline void took(int path) { g_path[path].fetch_add(1, std::memory_order_relaxed); }
@@ -799,10 +799,33 @@ void launch_wgrad_c(const WgradArgs& w, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_kernel<CL, R1>), grid, dim3(256), kWgradLdsBytes, st, w);
 }
 
-// cl > 0: the LASTW forms (dh formed from a_{L-1} in registers); r1: the rank-1 form (cl == 1), 1 = tanh, 2 = sigmoid
-void launch_wgrad(const WgradArgs& w, dim3 grid, int cl, int r1, hipStream_t st) {
+// wgrad2_kernel (two waves per SIMD, operands straight into registers) where it has the form: the plain weight gradient and
+// the rank-1 LASTW forms.  SVAE_WGRAD2=0 keeps wgrad_kernel everywhere (read per call: tests compare the two in one process).
+bool use_wgrad2(int cl, int r1) {
+    const char* e = getenv("SVAE_WGRAD2");
+    if (e && e[0] == '0') return false;
+    return cl == 0 || r1 != 0;
+}
+
+// cl > 0: the LASTW forms (dh formed from a_{L-1} in registers); r1: the rank-1 form (cl == 1), 1 = tanh, 2 = sigmoid.
+// nsplit row-range splits (the plan's wg_S: slab / bslab / wpart / bpart are sized for it); xcd: 1-D XCD-aware grid if it fits
+void launch_wgrad(WgradArgs w, int nsplit, bool xcd, int cl, int r1, hipStream_t st) {
     took(P_WGRAD_FP32);
     Scope prof(K_WGRAD, st);
+    const int ntile = w.Hp / 32;
+    if (use_wgrad2(cl, r1)) {
+        took(P_WGRAD2);
+        const int nb2 = ((ntile + 3) / 4) * ((ntile + 7) / 8);
+        w.S = (xcd && nb2 > 1 && nsplit % 8 == 0) ? nsplit : 0;
+        const dim3 grid = w.S ? dim3(nb2 * nsplit) : dim3(nb2, nsplit);
+        if (r1 == 1) hipLaunchKernelGGL((wgrad2_kernel<1>), grid, dim3(256), 0, st, w);
+        else if (r1 == 2) hipLaunchKernelGGL((wgrad2_kernel<2>), grid, dim3(256), 0, st, w);
+        else hipLaunchKernelGGL((wgrad2_kernel<0>), grid, dim3(256), 0, st, w);
+        return;
+    }
+    const int nb2 = w.nblk1 * w.nblk1;
+    w.S = (xcd && nb2 > 1 && nsplit % 8 == 0) ? nsplit : 0;
+    const dim3 grid = w.S ? dim3(nb2 * nsplit) : dim3(nb2, nsplit);
     if (r1 == 1) {
         launch_wgrad_c<1, 1>(w, grid, st);
         return;
@@ -1112,10 +1135,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                                    split_ob && l == g.L - 1, st);
             else {
                 static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
-                const int nb2 = pl.wg_nblk1 * pl.wg_nblk1;
-                w.S = (xcd_grid && nb2 > 1 && pl.wg_S % 8 == 0) ? pl.wg_S : 0;
-                launch_wgrad(w, w.S ? dim3(nb2 * pl.wg_S) : dim3(nb2, pl.wg_S), last ? g.C : 0,
-                             (last && r1) ? (g.act == SVAE_ACT_TANH ? 1 : 2) : 0, st);
+                launch_wgrad(w, pl.wg_S, xcd_grid, last ? g.C : 0, (last && r1) ? (g.act == SVAE_ACT_TANH ? 1 : 2) : 0, st);
             }
             hipStream_t ls = st;
             Scope prof(K_WGRAD_REDUCE, ls);

@@ -170,5 +170,5 @@ if __name__ == '__main__':
     s = open(sys.argv[1]).read()
     names = sys.argv[2:]
     if not names:
-        names = sorted(set(re.findall(r'^(_ZN4svae\d+(?:dense_kernel|dense4_kernel|dense4_dual_kernel|wgrad_kernel|split_wgrad_kernel|dense_split\w*_kernel)\w+):', s, re.M)))
+        names = sorted(set(re.findall(r'^(_ZN4svae\d+(?:dense_kernel|dense4_kernel|dense4_dual_kernel|wgrad_kernel|wgrad2_kernel|split_wgrad_kernel|dense_split\w*_kernel)\w+):', s, re.M)))
     sys.exit(max(check(s, n) for n in names))

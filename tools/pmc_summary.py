@@ -16,7 +16,7 @@ for d in sys.argv[1:]:
     for r in csv.DictReader(open(t)):
         dur[r['Kernel_Name'][:48]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     for name in agg:
-        if 'dense' in name or 'wgrad_kernel' in name:
+        if 'dense' in name or 'wgrad_kernel' in name or 'wgrad2_kernel' in name:
             c = {k: sum(v) / len(v) for k, v in agg[name].items()}
             us = sum(dur[name]) / len(dur[name])
             line = "%-50s %8.1f us " % (name, us)

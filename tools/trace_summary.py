@@ -14,7 +14,7 @@ import sys
 def family(name):
     if "dense_kernel" in name or "dense4_" in name or "dense_split" in name:
         return "decoder GEMM fwd/dgrad"
-    if "wgrad_kernel" in name or "split_wgrad" in name:
+    if "wgrad_kernel" in name or "wgrad2_kernel" in name or "split_wgrad" in name:
         return "decoder GEMM wgrad"
     if name.startswith("Cijk") or "Cijk_" in name:
         return "encoder GEMM (hipBLASLt)"
