@@ -65,3 +65,42 @@ def test_every_baseline_config_has_a_bench_line(config, batch, kernel_min_frac):
     r = d["roofline"]
     assert r["kernel"] in ("dense_fwd", "dense_dgrad", "wgrad") and kernel_min_frac < r["frac"] < 1.0
     assert set(r["gemm_kernels_frac"]) == {"dense_fwd", "dense_dgrad", "wgrad"}
+
+
+def test_gemm_kernel_times_ride_on_the_launches():
+    """svae_profile_enable(1): the three GEMM launches carry their own start/stop events (no record packets between the
+    kernels); every launch must come back from svae_profile_read with a plausible duration, pools must recycle."""
+    import contextlib
+    import io
+
+    import numpy as np
+    import torch
+    import torch.nn as nn
+
+    import spatial_vae.models as models
+    from spatial_vae_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = models.SpatialGenerator(2, 128, num_layers=3, activation=nn.Tanh).to(dev)
+    n, B = 16, 8
+    x0, x1 = np.meshgrid(np.linspace(-1, 1, n), np.linspace(1, -1, n))
+    grid = torch.from_numpy(np.stack([x0.ravel(), x1.ravel()], 1).astype(np.float32)).to(dev)
+    theta = torch.zeros(B, device=dev, requires_grad=True)
+    z = torch.randn(B, 2, device=dev, requires_grad=True)
+    _lib.profile_enable(1)
+    _lib.profile_read()
+    try:
+        for rounds in (1, 3):
+            for _ in range(rounds):
+                y = p.forward_posed(grid, B, theta=theta, dx=None, z=z)
+                y.sum().backward()
+            torch.cuda.synchronize()
+            prof = _lib.profile_read()
+            assert set(prof) == {"dense_fwd", "dense_dgrad", "wgrad"}, prof
+            for k, (ms, launches) in prof.items():
+                assert launches == 2 * rounds, (k, launches)          # L = 3: two hidden-layer GEMMs of each role per pass
+                assert 0.0 < ms / launches < 5.0, (k, ms, launches)   # a real kernel duration: not 0, not garbage
+    finally:
+        _lib.profile_enable(0)
+        _lib.profile_read()
