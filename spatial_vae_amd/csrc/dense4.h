@@ -18,8 +18,8 @@
 // ACTUAL 32-row tile of the group (tiles never straddle images: the per-tile reductions of the FIRST epilogue carry over).
 // Numerics: per output element the same k-ordered fma chain as dense_kernel; the plain forward is bit-identical to it
 // (tools/dense4_proto.hip).  Measured on random data (same tool, MI355X): H = 500, 204 800 rows 0.856 -> 0.802 ms; H = 1024
-// 0.536 -> 0.483 ms; at 51 200 rows (BASELINE cfg 1) the coarser work quantum loses (0.240 -> 0.247 ms), so small launches
-// stay with dense_kernel (use_dense4 in api.hip).
+// 0.536 -> 0.483 ms; at 51 200 rows (BASELINE cfg 1) the NT = 2 form's coarser work quantum loses (0.240 -> 0.247 ms) and the
+// half-width form NT = 1 (three waves per SIMD) is taken instead (use_dense4 in api.hip).
 #pragma once
 #include "dense.h"
 
@@ -36,8 +36,6 @@ template <int N>
 __device__ __forceinline__ void wait_vm4(f32x4v& v) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "i"(N) : "memory");
 }
-// act'(a) of the rank-1 output-layer forms for four row operands in two packed instructions (one fma per element costs ~5 %
-// of the launch here, the packed form ~4 %: tools/dense4_proto.hip): tanh 1 - a^2, sigmoid a - a^2
 // act'(a) of the rank-1 output-layer forms for the four row operands of a k-step: tanh 1 - a^2, sigmoid a - a^2.  Plain fma's
 // that the compiler sees (it may pack them itself): r03 tried the packed form from inline asm (v_pk_fma_f32 x 2).  It is ~0.7 %
 // faster in isolation (tools/dense4_proto.hip) but an MFMA may read a VGPR written by a packed-fp32 instruction only two wait
