@@ -1170,8 +1170,7 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                 static const bool xcd_grid = [] { const char* e = getenv("SVAE_XCD_GRID"); return !(e && e[0] == '0'); }();
                 launch_wgrad(w, pl.wg_S, xcd_grid, last ? g.C : 0, (last && r1) ? (g.act == SVAE_ACT_TANH ? 1 : 2) : 0, st);
             }
-            hipStream_t ls = st;
-            Scope prof(K_WGRAD_REDUCE, ls);
+            Scope prof(K_WGRAD_REDUCE, st);
             const bool db_elsewhere = split_ob && l == g.L - 1 && split_wgrad_on();  // out_bwd_split summed dh's columns
             const WgradReduceArgs ra{pl.slab, pl.bslab, grads->hidden_w[l - 1],
                                      db_elsewhere ? (float*)nullptr : grads->hidden_b[l - 1], g.H, g.Hp, pl.wg_S,
@@ -1182,13 +1181,13 @@ int svae_decoder_backward(const svae_desc* d, const svae_params* p, const svae_p
                 tail_r = ra;
                 tail_pending = true;
             } else {
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)g.H * g.H + 63) / 64)), dim3(256), 0, ls, ra);
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)g.H * g.H + 63) / 64)), dim3(256), 0, st, ra);
             }
             if (db_elsewhere && grads->hidden_b[l - 1])
-                hipLaunchKernelGGL(colsum_reduce_kernel, dim3(g.Hp / 32), dim3(256), 0, ls, pl.hbpart, grads->hidden_b[l - 1],
+                hipLaunchKernelGGL(colsum_reduce_kernel, dim3(g.Hp / 32), dim3(256), 0, st, pl.hbpart, grads->hidden_b[l - 1],
                                    g.H, g.Hp, ob_nparts);
             if (last)
-                hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, ls, pl.wpart, pl.bpart,
+                hipLaunchKernelGGL(out_bwd_reduce_kernel, dim3(g.C * ((g.Hp + 63) / 64) + 1), dim3(1024), 0, st, pl.wpart, pl.bpart,
                                    grads->out_w, grads->out_b, g.C, g.H, g.Hp, pl.wg_S * 2);
         }
         DenseArgs a;
