@@ -231,3 +231,53 @@ def test_bench_workload_tracks_the_cpu_port_over_adam_steps():
     for k, v in q_net.state_dict().items():
         assert rel_err(v.cpu().numpy(), cpu.qp[k].detach().numpy()) < 1e-4, k
     assert moved > 1e-3
+
+
+def test_bench_workload_stays_with_the_cpu_port_over_twenty_adam_steps():
+    """The same pairing over 20 updates at lr 1e-3 (the ELBO moves by hundreds of units; 40 steps were run once by hand:
+    profiles/r03_cpu_port_drift_40.json, max relative metric difference 2.3e-7): no systematic drift between the HIP step
+    and the CPU port of the reference step -- rounding differences may amplify, a wrong gradient component would separate the
+    two trajectories by orders of magnitude more.  The trajectories go to gpurun_out/ (kept as profiles/rNN_cpu_port_drift.json)."""
+    import json
+    import os
+
+    import bench
+    from oracle import torch_cpu_step as T
+    from spatial_vae_amd import dp, elbo as E
+    cfg = dict(bench.CONFIGS[2])
+    dev = torch.device("cuda:0")
+    p_net, q_net = bench.build_nets(cfg)
+    p_state = {k: v.detach().clone().numpy() for k, v in p_net.state_dict().items()}
+    q_state = {k: v.detach().clone().numpy() for k, v in q_net.state_dict().items()}
+    grid = bench.coord_grid(cfg["n"], cfg["n"])
+    rs = np.random.RandomState(9)
+    steps, lr = 20, 1e-3
+    ys = [torch.from_numpy(bench.synthetic_targets(cfg, rs, cfg["B"])) for _ in range(4)]
+    noise = torch.from_numpy(rs.normal(size=(steps, cfg["B"], bench.inf_dim(cfg))).astype(np.float32))
+    cpu = T.CpuTrainer(p_state, q_state, grid, lr=lr, script="mnist", act="tanh", rotate=True, translate=True,
+                       dx_scale=bench.DX_SCALE, theta_prior=cfg["theta_prior"])
+    p_net.to(dev)
+    q_net.to(dev)
+    step = dp.TrainStep(p_net, q_net, E.eval_minibatch_mnist, lr=lr, rotate=True, translate=True, dx_scale=bench.DX_SCALE,
+                        theta_prior=cfg["theta_prior"])
+    x = torch.from_numpy(grid).to(dev)
+    ys_dev = [y.to(dev) for y in ys]
+    noise_dev = noise.to(dev)
+    want, got = [], []
+    for i in range(steps):
+        want.append([float(v) for v in cpu.step(ys[i % 4], noise[i])])
+        step(x, ys_dev[i % 4], noise=noise_dev[i])
+        got.append(step.metrics.detach().cpu().numpy().astype(np.float64).tolist())
+    want, got = np.array(want), np.array(got)
+    rel = np.abs(got - want).max(axis=1) / np.abs(want).max(axis=1)
+    p_err = max(rel_err(v.cpu().numpy(), cpu.pp[k].detach().numpy()) for k, v in p_net.state_dict().items())
+    q_err = max(rel_err(v.cpu().numpy(), cpu.qp[k].detach().numpy()) for k, v in q_net.state_dict().items())
+    record = {"steps": steps, "lr": lr, "elbo_first": want[0][0], "elbo_last_cpu_port": want[-1][0], "elbo_last_hip": got[-1][0],
+              "max_rel_metric_diff": float(rel.max()), "rel_metric_diff_at_last_step": float(rel[-1]),
+              "max_param_rel_err_p_net": float(p_err), "max_param_rel_err_q_net": float(q_err)}
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "cpu_port_drift.json"), "w") as f:
+            json.dump(record, f)
+    assert abs(want[-1][0] - want[0][0]) > 1.0, record                    # the run went somewhere
+    assert rel.max() < 2e-5 and p_err < 1e-3 and q_err < 1e-3, record     # and the two went there together
