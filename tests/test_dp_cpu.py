@@ -60,7 +60,7 @@ packed = torch.cat([mine[o:o + p.numel()] for p, o in zip(step.grads.params, ste
 err = (packed - ref).abs().max().item() / ref.abs().max().item()
 both = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(both, mine)
-assert torch.equal(both[0], both[1]), "replicas diverged"
+assert all(torch.equal(both[0], b) for b in both[1:]), "replicas diverged"
 assert step.aliased()
 assert all(torch.equal(p.detach().reshape(-1), step.grads.flat_param[o:o + p.numel()]) for p, o in
            zip(step.grads.params, step.grads.offsets))
@@ -71,7 +71,7 @@ dist.destroy_process_group()
 '''
 
 
-def _run(tmp_path, bucketed):
+def _run(tmp_path, bucketed, world=2):
     sys.path.insert(0, ROOT)
     from spatial_vae_amd import dp
     script = tmp_path / "dp_step_worker.py"
@@ -80,11 +80,11 @@ def _run(tmp_path, bucketed):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     code = ("import sys; sys.path.insert(0, %r); from spatial_vae_amd import dp; "
-            "sys.exit(dp.launch_ranks(2, [%r]))" % (ROOT, str(script)))
+            "sys.exit(dp.launch_ranks(%d, [%r]))" % (ROOT, world, str(script)))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("rank")]
-    assert len(lines) == 2
+    assert len(lines) == world
     assert len({l.split()[3] for l in lines}) == 1, "ranks disagree on the shared seed: %r" % lines
 
 
@@ -94,6 +94,12 @@ def test_trainstep_world2_matches_single_process_one_bucket(tmp_path):
 
 def test_trainstep_world2_matches_single_process_two_buckets(tmp_path):
     _run(tmp_path, bucketed=True)
+
+
+def test_trainstep_world4_matches_single_process(tmp_path):
+    """Four ranks (the driver's scaling run goes to eight): the global batches of 8, 5, 1 and 6 rows shard as 2+2+2+2, 2+1+1+1,
+    1+0+0+0 (three ranks with NO rows join the collectives with zeros) and 2+2+1+1."""
+    _run(tmp_path, bucketed=True, world=4)
 
 
 def test_launch_ranks_reports_a_failing_rank(tmp_path):
