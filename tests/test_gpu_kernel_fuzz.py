@@ -5,6 +5,8 @@ either block width -- and compares all outputs.  The ISA
 check of the hand-issued loads (tools/check_asm_loads.py) is static; this is its dynamic counterpart: shapes nobody picked by
 hand (ragged tile counts, 1-3 octet row ranges per split, every activation, 1-4 layers, 1-3 channels, posed / explicit
 coordinates, z_dim 0) must give the same numbers whichever kernels run."""
+import os
+
 import numpy as np
 import pytest
 import torch.nn as nn
@@ -35,7 +37,8 @@ def _cases(count, seed):
     return out
 
 
-CASES = _cases(28, 20261005)
+# SVAE_FUZZ_COUNT widens the sweep for a one-off soak run (profiles/r03_kernel_fuzz_soak.txt: 400 geometries)
+CASES = _cases(int(os.environ.get("SVAE_FUZZ_COUNT", "28")), 20261005)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -47,7 +50,6 @@ def test_every_kernel_choice_gives_the_same_numbers(case, monkeypatch):
     monkeypatch.delenv("SVAE_WGRAD2")
     monkeypatch.delenv("SVAE_TAIL_MERGE")
     monkeypatch.delenv("SVAE_DENSE4", raising=False)
-    import os
     runs = {}
     # (SVAE_DENSE4, SVAE_TAIL_MERGE): the default dispatch with and without the merged tail launch, then dense4_kernel forced
     # at either block width wherever it is legal (small shapes take dense_kernel by default)
@@ -59,7 +61,7 @@ def test_every_kernel_choice_gives_the_same_numbers(case, monkeypatch):
         L = case[5]
         if L >= 2:
             assert c_new.get("wgrad2", 0) == L - 1, c_new
-        tol = 1e-5 if case[4] >= 200 else 3e-6
+        tol = 1e-5      # blocked fp32 sums over up to 12 k rows in different orders (the goldens allow 2e-5)
         for k in old:
             assert rel_err(new[k], old[k]) < tol, (case[0], d4, merge, k, rel_err(new[k], old[k]))
     for k in runs[("", "1")]:   # where the split-K reduction runs does not change a bit
