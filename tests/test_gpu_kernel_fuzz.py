@@ -17,7 +17,7 @@ from test_gpu_dense4 import _run
 pytestmark = pytest.mark.gpu
 
 
-def _cases(count, seed):
+def _cases(count, seed, big=False):
     rs = np.random.RandomState(seed)
     acts = [nn.Tanh, nn.Tanh, nn.Sigmoid, nn.ReLU, nn.LeakyReLU]
     out = []
@@ -29,6 +29,11 @@ def _cases(count, seed):
         if H >= 200:
             B = min(B, 6)
         L = int(rs.randint(1, 5))
+        if big:      # one-off soak at sizes where the wide / dual launches and long register-ring trips are what runs
+            n = int(rs.choice([28, 32, 40]))
+            B = int(rs.randint(24, 200))
+            H = int(rs.choice([200, 256, 500, 512]))
+            L = int(rs.randint(2, 4))
         C = int(rs.randint(1, 4))
         act = acts[int(rs.randint(len(acts)))]
         posed = bool(rs.randint(2))
@@ -38,7 +43,7 @@ def _cases(count, seed):
 
 
 # SVAE_FUZZ_COUNT widens the sweep for a one-off soak run (profiles/r03_kernel_fuzz_soak.txt: 400 geometries)
-CASES = _cases(int(os.environ.get("SVAE_FUZZ_COUNT", "28")), 20261005)
+CASES = _cases(int(os.environ.get("SVAE_FUZZ_COUNT", "28")), 20261005, big=os.environ.get("SVAE_FUZZ_BIG") == "1")
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
